@@ -1,0 +1,285 @@
+"""ctypes binding of the C ABI declared in include/hope_gpu.h.
+
+The same binding drives the HIP library (prefix ``hope_``, hope_amd/csrc/libhope_hip.so)
+and, in tests and the bench's cpu_baseline leg only, the CPU oracle (prefix
+``hope_oracle_``, oracle/_build/libhope_oracle.so).  Nothing in this package loads the
+oracle: callers that want it pass its path and prefix explicitly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HOPE_OK = 0
+HOPE_EMPTY = 1
+HOPE_NO_NORMAL_FIT = 2
+HOPE_MODE_OFFLINE = 0
+HOPE_MODE_RT = 1
+
+REPO_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIP_LIB_PATH = os.path.join(REPO_ROOT, "hope_amd", "csrc", "libhope_hip.so")
+
+
+class HopeConfig(C.Structure):
+    _fields_ = [
+        ("th_xy", C.c_float), ("th_z", C.c_float),
+        ("min_depth", C.c_float), ("max_depth", C.c_float),
+        ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+        ("depth_scale", C.c_float),
+        ("knn", C.c_int32), ("min_cluster", C.c_int32), ("mode", C.c_int32),
+        ("min_height", C.c_float), ("max_height", C.c_float),
+        ("aggressive_merge", C.c_int32), ("device", C.c_int32),
+        ("reserved", C.c_int32 * 4),
+    ]
+
+
+class HopeCounts(C.Structure):
+    _fields_ = [
+        ("n_in", C.c_int64), ("n_raw", C.c_int64), ("n_vox", C.c_int64), ("n_fit", C.c_int64),
+        ("n_segments", C.c_int32), ("n_clusters", C.c_int32), ("n_planes", C.c_int32),
+        ("grid", C.c_int32 * 3), ("min_b", C.c_int32 * 3),
+        ("vox_passthrough", C.c_int32), ("status", C.c_int32),
+        ("reserved", C.c_int32 * 3),
+    ]
+
+
+class HopeCluster(C.Structure):
+    _fields_ = [
+        ("size", C.c_int32), ("pass_", C.c_int32), ("z_mean", C.c_float),
+        ("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float),
+        ("seed_rank", C.c_int32),
+    ]
+
+
+class HopeMaxPlane(C.Structure):
+    _fields_ = [
+        ("valid", C.c_int32), ("n_points", C.c_int32), ("z", C.c_float),
+        ("n_members", C.c_int32), ("members", C.c_int32 * 16),
+    ]
+
+
+CLUSTER_DTYPE = np.dtype([
+    ("size", "<i4"), ("pass", "<i4"), ("z_mean", "<f4"),
+    ("min_x", "<f4"), ("min_y", "<f4"), ("max_x", "<f4"), ("max_y", "<f4"),
+    ("seed_rank", "<i4"),
+])
+assert CLUSTER_DTYPE.itemsize == C.sizeof(HopeCluster)
+
+# every symbol include/hope_gpu.h declares (without prefix)
+ABI_SYMBOLS = [
+    "config_default", "create", "destroy", "last_error", "set_pose", "set_frame_poses",
+    "set_height_window", "segment_depth_u16", "segment_cloud_xyz", "num_frames",
+    "frame_counts", "get_transformed", "get_downsampled", "get_normals", "get_fit_indices",
+    "get_knn", "get_labels", "get_clusters", "get_cluster_indices", "get_max_plane",
+    "last_timing",
+]
+
+
+class HopeError(RuntimeError):
+    pass
+
+
+class HopeLib:
+    """A loaded implementation of the C ABI."""
+
+    def __init__(self, path=HIP_LIB_PATH, prefix="hope_"):
+        if not os.path.exists(path):
+            raise HopeError(
+                f"{path} is missing: build it first (python -c 'import __graft_entry__ as g; g.build()' "
+                "or make -C hope_amd/csrc). There is no CPU fallback.")
+        self.path = path
+        self.prefix = prefix
+        self.dll = C.CDLL(path, mode=C.RTLD_LOCAL)
+        vp, i32, f32p = C.c_void_p, C.c_int, C.POINTER(C.c_float)
+        sig = {
+            "config_default": (C.c_int, [C.POINTER(HopeConfig)]),
+            "create": (C.c_int, [C.POINTER(HopeConfig), C.POINTER(vp)]),
+            "destroy": (None, [vp]),
+            "last_error": (C.c_char_p, [vp]),
+            "set_pose": (C.c_int, [vp, f32p, f32p]),
+            "set_frame_poses": (C.c_int, [vp, i32, f32p, f32p]),
+            "set_height_window": (C.c_int, [vp, C.c_float, C.c_float]),
+            "segment_depth_u16": (C.c_int, [vp, vp, i32, i32, i32, i32]),
+            "segment_cloud_xyz": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, i32, i32]),
+            "num_frames": (C.c_int, [vp]),
+            "frame_counts": (C.c_int, [vp, i32, C.POINTER(HopeCounts)]),
+            "get_transformed": (C.c_int, [vp, i32, vp, vp]),
+            "get_downsampled": (C.c_int, [vp, i32, vp]),
+            "get_normals": (C.c_int, [vp, i32, vp]),
+            "get_fit_indices": (C.c_int, [vp, i32, vp]),
+            "get_knn": (C.c_int, [vp, i32, vp]),
+            "get_labels": (C.c_int, [vp, i32, vp]),
+            "get_clusters": (C.c_int, [vp, i32, vp, i32]),
+            "get_cluster_indices": (C.c_int, [vp, i32, i32, vp, i32]),
+            "get_max_plane": (C.c_int, [vp, i32, C.POINTER(HopeMaxPlane)]),
+            "last_timing": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        }
+        self.fn = {}
+        for name, (res, args) in sig.items():
+            f = getattr(self.dll, prefix + name)
+            f.restype = res
+            f.argtypes = args
+            self.fn[name] = f
+
+    def default_config(self):
+        cfg = HopeConfig()
+        self.fn["config_default"](C.byref(cfg))
+        return cfg
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class HopeContext:
+    """One hope_ctx.  Mirrors the life cycle of a PlaneSegment / PlaneSegmentRT object."""
+
+    def __init__(self, lib, **overrides):
+        self.lib = lib
+        cfg = lib.default_config()
+        for k, v in overrides.items():
+            if not hasattr(cfg, k):
+                raise AttributeError(k)
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        st = lib.fn["create"](C.byref(cfg), C.byref(self._h))
+        if st != 0:
+            raise HopeError(f"hope_create failed: {st}")
+
+    def close(self):
+        if self._h:
+            self.lib.fn["destroy"](self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st, what):
+        if st < 0:
+            msg = self.lib.fn["last_error"](self._h)
+            raise HopeError(f"{what} failed ({st}): {msg.decode() if msg else ''}")
+        return st
+
+    # -- pose / parameters ---------------------------------------------------------------
+    def set_pose(self, t, q):
+        t, q = _f32(t), _f32(q)
+        assert t.shape == (3,) and q.shape == (4,)
+        fp = C.POINTER(C.c_float)
+        self._check(self.lib.fn["set_pose"](self._h, t.ctypes.data_as(fp), q.ctypes.data_as(fp)), "set_pose")
+
+    def set_frame_poses(self, t, q):
+        t, q = _f32(t), _f32(q)
+        n = t.shape[0]
+        assert t.shape == (n, 3) and q.shape == (n, 4)
+        fp = C.POINTER(C.c_float)
+        self._check(self.lib.fn["set_frame_poses"](self._h, n, t.ctypes.data_as(fp), q.ctypes.data_as(fp)),
+                    "set_frame_poses")
+
+    def set_height_window(self, lo, hi):
+        self._check(self.lib.fn["set_height_window"](self._h, lo, hi), "set_height_window")
+
+    # -- hot path ------------------------------------------------------------------------
+    def segment_depth(self, depth):
+        """depth: uint16 numpy array [n_frames, h, w] or [h, w]."""
+        d = np.ascontiguousarray(depth, dtype=np.uint16)
+        if d.ndim == 2:
+            d = d[None]
+        n, h, w = d.shape
+        return self._check(self.lib.fn["segment_depth_u16"](self._h, d.ctypes.data, w, h, n, 0), "segment_depth_u16")
+
+    def segment_depth_device(self, dev_ptr, w, h, n_frames):
+        """depth already resident in HBM (raw device pointer, e.g. torch tensor.data_ptr())."""
+        return self._check(self.lib.fn["segment_depth_u16"](self._h, dev_ptr, w, h, n_frames, 1),
+                           "segment_depth_u16")
+
+    def segment_cloud(self, xyz, apply_filter_transform=False):
+        """xyz: float32 [n, c] with c >= 3 (row stride c*4 bytes)."""
+        a = np.ascontiguousarray(xyz, dtype=np.float32)
+        assert a.ndim == 2 and a.shape[1] >= 3
+        return self._check(
+            self.lib.fn["segment_cloud_xyz"](self._h, a.ctypes.data, a.shape[0], a.shape[1] * 4,
+                                             1 if apply_filter_transform else 0, 0), "segment_cloud_xyz")
+
+    def segment_cloud_device(self, dev_ptr, n, stride_bytes, apply_filter_transform=False):
+        return self._check(
+            self.lib.fn["segment_cloud_xyz"](self._h, dev_ptr, n, stride_bytes,
+                                             1 if apply_filter_transform else 0, 1), "segment_cloud_xyz")
+
+    # -- results -------------------------------------------------------------------------
+    def num_frames(self):
+        return self.lib.fn["num_frames"](self._h)
+
+    def counts(self, frame=0):
+        c = HopeCounts()
+        self._check(self.lib.fn["frame_counts"](self._h, frame, C.byref(c)), "frame_counts")
+        return c
+
+    def transformed(self, frame=0):
+        n = self.counts(frame).n_raw
+        xyz = np.empty((n, 3), np.float32)
+        src = np.empty((n,), np.int32)
+        self._check(self.lib.fn["get_transformed"](self._h, frame, xyz.ctypes.data, src.ctypes.data), "get_transformed")
+        return xyz, src
+
+    def downsampled(self, frame=0):
+        n = self.counts(frame).n_vox
+        xyz = np.empty((n, 3), np.float32)
+        if n:
+            self._check(self.lib.fn["get_downsampled"](self._h, frame, xyz.ctypes.data), "get_downsampled")
+        return xyz
+
+    def normals(self, frame=0):
+        n = self.counts(frame).n_vox
+        out = np.empty((n, 4), np.float32)
+        if n:
+            self._check(self.lib.fn["get_normals"](self._h, frame, out.ctypes.data), "get_normals")
+        return out
+
+    def fit_indices(self, frame=0):
+        n = self.counts(frame).n_fit
+        out = np.empty((n,), np.int32)
+        if n:
+            self._check(self.lib.fn["get_fit_indices"](self._h, frame, out.ctypes.data), "get_fit_indices")
+        return out
+
+    def knn(self, frame=0):
+        n = self.counts(frame).n_fit
+        out = np.empty((n, self.cfg.knn), np.int32)
+        if n:
+            self._check(self.lib.fn["get_knn"](self._h, frame, out.ctypes.data), "get_knn")
+        return out
+
+    def labels(self, frame=0):
+        n = self.counts(frame).n_fit
+        out = np.empty((n,), np.int32)
+        if n:
+            self._check(self.lib.fn["get_labels"](self._h, frame, out.ctypes.data), "get_labels")
+        return out
+
+    def clusters(self, frame=0):
+        n = self.counts(frame).n_clusters
+        out = np.zeros((n,), CLUSTER_DTYPE)
+        if n:
+            got = self._check(self.lib.fn["get_clusters"](self._h, frame, out.ctypes.data, n), "get_clusters")
+            assert got == n
+        return out
+
+    def cluster_indices(self, frame, cluster, size):
+        out = np.empty((size,), np.int32)
+        got = self._check(self.lib.fn["get_cluster_indices"](self._h, frame, cluster, out.ctypes.data, size),
+                          "get_cluster_indices")
+        return out[:got]
+
+    def max_plane(self, frame=0):
+        m = HopeMaxPlane()
+        self._check(self.lib.fn["get_max_plane"](self._h, frame, C.byref(m)), "get_max_plane")
+        return m
+
+    def timing(self):
+        a, b = C.c_double(), C.c_double()
+        self.lib.fn["last_timing"](self._h, C.byref(a), C.byref(b))
+        return a.value, b.value

@@ -1,0 +1,176 @@
+/*
+ * hope_gpu.h — C ABI of the MI355X-native HoPE horizontal-plane extraction hot path.
+ *
+ * The reference (DrawZeroPoint/hope) has no FFI/plugin layer: its boundary is the C++
+ * class surface PlaneSegment / PlaneSegmentRT (src/lib/plane_segment.h:114-146,243-280).
+ * This header is the seam a maintainer binds *inside* those classes: everything between
+ * the input cloud / depth frame and the per-plane results, i.e. the block
+ * src/lib/plane_segment.cpp:123-159 (offline) and :755-764 + :791-795 (real-time).
+ * INTEGRATION.md shows the adapter code.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types; never throws across the boundary
+ *   - return value: 0 ok, >0 soft "nothing found" (the reference's warn+return paths),
+ *     <0 hard error (hope_last_error() gives the text)
+ *   - one ctx = one HIP stream + one workspace; a ctx is not thread-safe, but any number
+ *     of ctxs may be used concurrently (the reference's file-scope thresholds,
+ *     plane_segment.cpp:10-24, became ctx fields)
+ *   - results live inside the ctx until the next hope_segment_* call or hope_destroy()
+ *   - "frame" = one independent extraction problem; a depth batch has n_frames of them,
+ *     a cloud call has exactly one
+ *
+ * The CPU oracle (oracle/hope_oracle.cpp, test infrastructure only) exports the same
+ * functions under the prefix hope_oracle_.
+ */
+#ifndef HOPE_GPU_H
+#define HOPE_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define HOPE_API __attribute__((visibility("default")))
+#else
+#define HOPE_API
+#endif
+
+typedef struct hope_ctx hope_ctx;
+
+enum {
+  HOPE_OK = 0,
+  HOPE_EMPTY = 1,           /* down-sampled cloud empty (plane_segment.cpp:145-148,757-760) */
+  HOPE_NO_NORMAL_FIT = 2,   /* no point passed the |nz| gate (plane_segment.cpp:698,867-870) */
+  HOPE_E_INVALID = -1,      /* bad argument */
+  HOPE_E_HIP = -2,          /* HIP runtime error */
+  HOPE_E_NOMEM = -3,
+  HOPE_E_RANGE = -4         /* a frame index / capacity is out of range */
+};
+
+/* Which class's post-clustering semantics to apply. */
+enum {
+  HOPE_MODE_OFFLINE = 0,    /* PlaneSegment   (plane_segment.cpp:350-389) */
+  HOPE_MODE_RT = 1          /* PlaneSegmentRT (plane_segment.cpp:930-962): height window,
+                               aggressive merge, keep largest plane */
+};
+
+/* All parameters of the path; replaces the reference's globals and literals.
+ * Defaults (hope_config_default) are the values hard-coded upstream. */
+typedef struct hope_config {
+  float th_xy;            /* xy_resolution, hope_node.cpp:160 / hope_ros.cpp:22        (0.05) */
+  float th_z;             /* z_resolution,  hope_node.cpp:161 / hope_ros.cpp:23        (0.02) */
+  float min_depth;        /* th_min_depth_, plane_segment.cpp:19                       (0.3)  */
+  float max_depth;        /* th_max_depth_, plane_segment.cpp:20                       (8.0)  */
+  float fx, fy, cx, cy;   /* TUM intrinsics, get_cloud.cpp:215-217       (517,517,318.6,255.3) */
+  float depth_scale;      /* get_cloud.cpp:218                                         (5000) */
+  int32_t knn;            /* ZGrowing neighbours, plane_segment.cpp:333                (8)    */
+  int32_t min_cluster;    /* plane_segment.cpp:330                                     (3)    */
+  int32_t mode;           /* HOPE_MODE_*                                                     */
+  float min_height;       /* cfg/hope.cfg:14 min_height_cfg                            (0.8)  */
+  float max_height;       /* cfg/hope.cfg:15 max_height_cfg                            (1.5)  */
+  int32_t aggressive_merge; /* plane_segment.cpp:719                                   (1)    */
+  int32_t device;         /* HIP device ordinal (ignored by the oracle)                (0)    */
+  int32_t reserved[4];
+} hope_config;
+
+/* Per-frame stage sizes. */
+typedef struct hope_counts {
+  int64_t n_in;           /* pixels / input points                                   */
+  int64_t n_raw;          /* after range filter (A1/A2)                              */
+  int64_t n_vox;          /* after VoxelGrid (A5)                                    */
+  int64_t n_fit;          /* after |nz| > th_norm (A7)                               */
+  int32_t n_segments;     /* ZGrowing segments before the size filter (A9)           */
+  int32_t n_clusters;     /* segments with size >= min_cluster (A9)                  */
+  int32_t n_planes;       /* clusters that passed normalAnalysis (+ RT height gate)  */
+  int32_t grid[3];        /* VoxelGrid div_b (A5)                                    */
+  int32_t min_b[3];       /* VoxelGrid min_b (A5)                                    */
+  int32_t vox_passthrough;/* 1 if PCL's "leaf size too small" rule copied the input  */
+  int32_t status;         /* HOPE_OK / HOPE_EMPTY / HOPE_NO_NORMAL_FIT for this frame */
+  int32_t reserved[3];
+} hope_counts;
+
+/* One ZGrowing cluster (in the reference's own cluster order = seed order). */
+typedef struct hope_cluster {
+  int32_t size;           /* number of member points                                 */
+  int32_t pass;           /* Utilities::normalAnalysis verdict, utilities.cpp:151-255 */
+  float z_mean;           /* getCloudZInfo, utilities.cpp:751-769                    */
+  float min_x, min_y, max_x, max_y; /* setFeatures, plane_segment.cpp:408-420        */
+  int32_t seed_rank;      /* position of the cluster's seed in the ZGrowing seed order */
+} hope_cluster;
+
+/* PlaneSegmentRT winner (plane_segment.cpp:953-960). */
+typedef struct hope_max_plane {
+  int32_t valid;          /* 0: no plane inside the height window                    */
+  int32_t n_points;       /* max_plane_points_num_ (merged count when aggressive)    */
+  float z;                /* max_plane_z_                                            */
+  int32_t n_members;      /* number of clusters whose points form max_plane_cloud_   */
+  int32_t members[16];    /* their cluster indices, in max_plane_cloud_ point order  */
+} hope_max_plane;
+
+/* ---- lifecycle ------------------------------------------------------------------- */
+HOPE_API int hope_config_default(hope_config* cfg);
+/* replaces PlaneSegment::PlaneSegment / PlaneSegmentRT::PlaneSegmentRT threshold set-up
+ * (plane_segment.cpp:46-50,721-725) */
+HOPE_API int hope_create(const hope_config* cfg, hope_ctx** out);
+HOPE_API void hope_destroy(hope_ctx* ctx);
+HOPE_API const char* hope_last_error(const hope_ctx* ctx);
+
+/* ---- pose / dynamic parameters --------------------------------------------------- */
+/* replaces PlaneSegment::setT + setQ (plane_segment.cpp:93-107) and the tf lookup result
+ * consumed by Transform::doTransform (transform.cpp:72-98); quaternion is NOT normalised,
+ * exactly like the reference. Applies to every frame. */
+HOPE_API int hope_set_pose(hope_ctx* ctx, const float t_xyz[3], const float q_xyzw[4]);
+/* per-frame poses for a depth batch (the TUM_LIST loop, hope_node.cpp:228-241) */
+HOPE_API int hope_set_frame_poses(hope_ctx* ctx, int n_frames, const float* t_xyz,
+                                  const float* q_xyzw);
+/* replaces PlaneSegmentRT::configCallback (plane_segment.cpp:798-801) */
+HOPE_API int hope_set_height_window(hope_ctx* ctx, float min_height, float max_height);
+
+/* ---- the hot path ---------------------------------------------------------------- */
+/* Fused A1..A12 on TUM-style depth frames: replaces GetCloud::getColorCloud
+ * (get_cloud.cpp:207-245) + PlaneSegment::getHorizontalPlanes (plane_segment.cpp:110-159).
+ * depth: n_frames*h*w uint16, row-major; on_device != 0 means a HIP device pointer. */
+HOPE_API int hope_segment_depth_u16(hope_ctx* ctx, const uint16_t* depth, int w, int h,
+                                    int n_frames, int on_device);
+/* A2..A12 on a point cloud: replaces getHorizontalPlanes for POINT_CLOUD input
+ * (apply_filter_transform = 0, plane_segment.cpp:118-120) and the RT callback + loop
+ * (apply_filter_transform = 1, plane_segment.cpp:749-766,778-796).
+ * xyz: n points, each the first 3 floats of a record of stride_bytes bytes
+ * (12 = packed, 16 = pcl::PointXYZ, 32 = pcl::PointXYZRGB). */
+HOPE_API int hope_segment_cloud_xyz(hope_ctx* ctx, const void* xyz, size_t n,
+                                    size_t stride_bytes, int apply_filter_transform,
+                                    int on_device);
+
+/* ---- results (host buffers supplied by the caller) -------------------------------- */
+HOPE_API int hope_num_frames(const hope_ctx* ctx);
+HOPE_API int hope_frame_counts(hope_ctx* ctx, int frame, hope_counts* out);
+/* src_mono_cloud_ after A3 (n_raw*3 floats) and the source index of each point */
+HOPE_API int hope_get_transformed(hope_ctx* ctx, int frame, float* xyz, int32_t* src_index);
+/* src_sp_mono_ / src_dsp_mono_ (n_vox*3 floats, PCL VoxelGrid order) */
+HOPE_API int hope_get_downsampled(hope_ctx* ctx, int frame, float* xyz);
+/* src_normals_ (n_vox*4 floats: nx,ny,nz,curvature) */
+HOPE_API int hope_get_normals(hope_ctx* ctx, int frame, float* nxyzc);
+/* idx_norm_fit_ (n_fit int32 indices into the down-sampled cloud) */
+HOPE_API int hope_get_fit_indices(hope_ctx* ctx, int frame, int32_t* idx);
+/* ZGrowing::point_neighbours_ (n_fit*knn int32, -1 padded when n_fit < knn) */
+HOPE_API int hope_get_knn(hope_ctx* ctx, int frame, int32_t* nbr);
+/* per fit point: index into the cluster list (seed order, after the size filter), -1 none */
+HOPE_API int hope_get_labels(hope_ctx* ctx, int frame, int32_t* labels);
+/* seed_clusters_indices_ summary; returns the number of clusters written (<= cap) */
+HOPE_API int hope_get_clusters(hope_ctx* ctx, int frame, hope_cluster* out, int cap);
+/* seed_clusters_indices_[cluster].indices (ascending, into the fit cloud) */
+HOPE_API int hope_get_cluster_indices(hope_ctx* ctx, int frame, int cluster, int32_t* idx,
+                                      int cap);
+/* PlaneSegmentRT::max_plane_* */
+HOPE_API int hope_get_max_plane(hope_ctx* ctx, int frame, hope_max_plane* out);
+/* wall-clock of the last segment call in ms: whole path, and the reference's own timer
+ * window (findAllPlanes only, plane_segment.cpp:157-169) */
+HOPE_API int hope_last_timing(hope_ctx* ctx, double* whole_ms, double* ref_window_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HOPE_GPU_H */
