@@ -1,0 +1,883 @@
+// hope_hip.hip — host side of the C ABI (include/hope_gpu.h): owns the HIP stream and the
+// HBM workspace, launches the kernels of kernels.hpp in pipeline order and keeps the
+// results resident until the next call.  No CPU fallback: every stage runs on the GPU.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "prims.hpp"
+
+using namespace hope;
+
+static_assert(sizeof(ClusterRec) == sizeof(hope_cluster), "ClusterRec must mirror hope_cluster");
+
+namespace {
+
+struct Pose {
+  float t[3];
+  float q[4];
+};
+
+// Grow-only HBM workspace: blocks are kept across calls, so after the first call of a
+// given shape no hipMalloc happens on the hot path.
+struct Arena {
+  struct Block {
+    char* p;
+    size_t cap, used;
+  };
+  std::vector<Block> blocks;
+  size_t min_block = (size_t)256 << 20;
+  bool failed = false;
+
+  void reset()
+  {
+    for (Block& b : blocks) b.used = 0;
+    failed = false;
+  }
+  void* alloc(size_t bytes)
+  {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    for (Block& b : blocks) {
+      if (b.cap - b.used >= bytes) {
+        void* r = b.p + b.used;
+        b.used += bytes;
+        return r;
+      }
+    }
+    Block nb;
+    nb.cap = std::max(bytes, min_block);
+    nb.used = bytes;
+    nb.p = nullptr;
+    if (hipMalloc((void**)&nb.p, nb.cap) != hipSuccess || !nb.p) {
+      (void)hipGetLastError();
+      failed = true;
+      return nullptr;
+    }
+    blocks.push_back(nb);
+    return nb.p;
+  }
+  void release()
+  {
+    for (Block& b : blocks) (void)hipFree(b.p);
+    blocks.clear();
+  }
+};
+
+void* arena_alloc_cb(void* user, size_t bytes) { return static_cast<Arena*>(user)->alloc(bytes); }
+
+inline int bits_for(unsigned long long v)  // bits needed to represent values 0..v
+{
+  int b = 1;
+  while (b < 64 && (v >> b) != 0) ++b;
+  return b;
+}
+
+inline unsigned nblk(size_t n, int per = kBlock) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+struct hope_ctx {
+  hope_config cfg;
+  float th_theta = 0, th_angle = 0, th_norm = 0;
+  float inv_xy = 0, inv_z = 0;
+  float radius = 0, r2 = 0;
+  int ring = 2;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr;
+  Arena arena;
+  Globals* d_glob = nullptr;
+  Globals* h_glob = nullptr;  // pinned
+  Pose pose;
+  std::vector<Pose> frame_poses;
+  std::string err;
+  double whole_ms = 0, ref_ms = 0;
+  int normals_cap_small = 0;  // test knob: force the neighbour-list overflow path
+
+  // ---- state of the last call --------------------------------------------------------
+  int n_frames = 0;
+  int src_kind = 0;  // 1 depth, 2 cloud
+  DepthSrc dsrc{};
+  CloudSrc csrc{};
+  std::vector<FrameInfo> h_fi;
+  std::vector<ClusterRec> h_rec;
+  std::vector<hope_max_plane> h_max;
+  std::vector<int> h_nplanes;
+  FrameInfo* d_fi = nullptr;
+  float4* d_vox = nullptr;
+  float4* d_normals = nullptr;
+  uint32_t* d_fit_idx = nullptr;
+  int* d_knn = nullptr;
+  int* d_cid = nullptr;
+  uint32_t* d_members = nullptr;
+  uint32_t* d_cl_first = nullptr;
+  unsigned n_vox_total = 0, n_fit_total = 0, n_cl_total = 0;
+};
+
+namespace {
+
+#define HIPCHK(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t e__ = (expr);                                                                 \
+    if (e__ != hipSuccess) {                                                                 \
+      char buf__[512];                                                                       \
+      snprintf(buf__, sizeof(buf__), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+               __FILE__, __LINE__);                                                          \
+      c->err = buf__;                                                                        \
+      return HOPE_E_HIP;                                                                     \
+    }                                                                                        \
+  } while (0)
+
+#define ALLOC(ptr, type, count)                                     \
+  do {                                                              \
+    ptr = static_cast<type*>(c->arena.alloc(sizeof(type) * (size_t)(count))); \
+    if (!ptr) {                                                     \
+      c->err = "out of device memory";                              \
+      return HOPE_E_NOMEM;                                          \
+    }                                                               \
+  } while (0)
+
+// thresholds exactly as the reference derives them (plane_segment.cpp:46-50; host scalars)
+void derive_thresholds(hope_ctx* c)
+{
+  c->th_theta = c->cfg.th_z / c->cfg.th_xy;
+  c->th_angle = std::atan(c->th_theta);
+  c->th_norm = (float)std::sqrt(1 / (1 + 2 * std::pow((double)c->th_theta, 2)));
+  c->inv_xy = 1.0f / c->cfg.th_xy;  // VoxelGrid inverse_leaf_size_
+  c->inv_z = 1.0f / c->cfg.th_z;
+  const float norm_r = (float)(1.01 * c->cfg.th_xy);  // plane_segment.cpp:695
+  const double radius = (double)norm_r;
+  c->radius = norm_r;
+  c->r2 = static_cast<float>(radius * radius);  // KdTreeFLANN::radiusSearch
+  c->ring = (int)std::floor(norm_r * c->inv_xy + 0.01f) + 1;
+}
+
+// Eigen Quaternion::toRotationMatrix on the un-normalised quaternion (transform.cpp:168-171)
+void make_affine(const Pose& p, float* a)
+{
+  const float x = p.q[0], y = p.q[1], z = p.q[2], w = p.q[3];
+  const float tx = 2.f * x, ty = 2.f * y, tz = 2.f * z;
+  const float twx = tx * w, twy = ty * w, twz = tz * w;
+  const float txx = tx * x, txy = ty * x, txz = tz * x;
+  const float tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  a[0] = 1.f - (tyy + tzz);
+  a[1] = txy - twz;
+  a[2] = txz + twy;
+  a[3] = txy + twz;
+  a[4] = 1.f - (txx + tzz);
+  a[5] = tyz - twx;
+  a[6] = txz - twy;
+  a[7] = tyz + twx;
+  a[8] = 1.f - (txx + tyy);
+  a[9] = p.t[0];
+  a[10] = p.t[1];
+  a[11] = p.t[2];
+}
+
+int sync_globals(hope_ctx* c)
+{
+  HIPCHK(hipMemcpyAsync(c->h_glob, c->d_glob, sizeof(Globals), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return HOPE_OK;
+}
+
+// PlaneSegmentRT::getPlane's winner logic over the cluster records (plane_segment.cpp:930-962)
+void rt_post(hope_ctx* c)
+{
+  c->h_max.assign(c->n_frames, hope_max_plane{});
+  c->h_nplanes.assign(c->n_frames, 0);
+  for (int f = 0; f < c->n_frames; ++f) {
+    const FrameInfo& F = c->h_fi[f];
+    hope_max_plane& mp = c->h_max[f];
+    mp.z = -1000.0f;
+    int n_planes = 0;
+    for (int ci = 0; ci < F.n_clusters; ++ci) {
+      const ClusterRec& r = c->h_rec[F.cl_start + ci];
+      if (c->cfg.mode == HOPE_MODE_OFFLINE) {
+        if (r.pass) ++n_planes;
+        continue;
+      }
+      const float z_in = r.z_mean;
+      if (!(z_in > c->cfg.min_height && z_in < c->cfg.max_height)) continue;
+      if (!r.pass) continue;
+      ++n_planes;
+      int members[17];
+      int nm = 0;
+      members[nm++] = ci;
+      int count = r.size;
+      if (c->cfg.aggressive_merge && mp.valid) {
+        if (std::fabs(mp.z - z_in) <= c->cfg.th_z) {
+          for (int m = 0; m < mp.n_members && nm < 16; ++m) members[nm++] = mp.members[m];
+          count += mp.n_points;
+        }
+      }
+      if (count > mp.n_points) {
+        mp.valid = 1;
+        mp.n_points = count;
+        mp.z = z_in;
+        mp.n_members = std::min(nm, 16);
+        for (int m = 0; m < mp.n_members; ++m) mp.members[m] = members[m];
+      }
+    }
+    c->h_nplanes[f] = n_planes;
+  }
+}
+
+template <class Src, class VK>
+int stage_voxel(hope_ctx* c, const Src& src, size_t n_per_frame, int cell_bits, int total_bits, float4*& d_vox,
+                int*& d_vox_frame)
+{
+  const int F = c->n_frames;
+  const size_t N = n_per_frame * (size_t)F;
+  hipStream_t s = c->stream;
+  PrimAlloc pa{arena_alloc_cb, &c->arena};
+  VK *k_in, *k_out, *uniq;
+  uint32_t *v_in, *v_out, *run_cnt, *run_start;
+  ALLOC(k_in, VK, N);
+  ALLOC(k_out, VK, N);
+  ALLOC(v_in, uint32_t, N);
+  ALLOC(v_out, uint32_t, N);
+  const unsigned bx = std::min<unsigned>(nblk(n_per_frame), 4096u);
+  hipLaunchKernelGGL((k_voxel_keys<Src, VK>), dim3(bx, F), dim3(kBlock), 0, s, src, c->d_fi, c->inv_xy, c->inv_z,
+                     cell_bits, F, k_in, v_in);
+  if (sizeof(VK) == 4) {
+    HIPCHK(sort_pairs_u32(pa, (const uint32_t*)k_in, (uint32_t*)k_out, v_in, v_out, N, total_bits, s));
+  } else {
+    HIPCHK(sort_pairs_u64(pa, (const uint64_t*)k_in, (uint64_t*)k_out, v_in, v_out, N, total_bits, s));
+  }
+  // k_in / v_in are dead now: reuse them for the run-length outputs
+  uniq = k_in;
+  run_cnt = v_in;
+  ALLOC(run_start, uint32_t, N + 1);
+  if (sizeof(VK) == 4) {
+    HIPCHK(rle_u32(pa, (const uint32_t*)k_out, N, (uint32_t*)uniq, run_cnt, &c->d_glob->n_runs, s));
+  } else {
+    HIPCHK(rle_u64(pa, (const uint64_t*)k_out, N, (uint64_t*)uniq, run_cnt, &c->d_glob->n_runs, s));
+  }
+  hipLaunchKernelGGL((k_frame_vox_ranges<VK>), dim3(nblk(F + 1)), dim3(kBlock), 0, s, c->d_fi, F, uniq,
+                     &c->d_glob->n_runs, cell_bits, c->d_glob);
+  hipLaunchKernelGGL(k_frame_vox_counts, dim3(nblk(F)), dim3(kBlock), 0, s, c->d_fi, F, c->d_glob);
+  int st = sync_globals(c);
+  if (st != HOPE_OK) return st;
+  const unsigned n_vox = c->h_glob->n_vox_total;
+  c->n_vox_total = n_vox;
+  if (n_vox == 0) return HOPE_OK;
+  HIPCHK(exclusive_scan_u32(pa, run_cnt, run_start, n_vox, s));
+  ALLOC(d_vox, float4, n_vox);
+  ALLOC(d_vox_frame, int, n_vox);
+  hipLaunchKernelGGL((k_centroids<Src, VK>), dim3(nblk(n_vox)), dim3(kBlock), 0, s, src, c->d_fi, uniq, run_start,
+                     run_cnt, v_out, n_vox, cell_bits, d_vox, d_vox_frame);
+  return HOPE_OK;
+}
+
+template <class CK>
+int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2_bits)
+{
+  const int F = c->n_frames;
+  const unsigned n_vox = c->n_vox_total;
+  const int K = c->cfg.knn;
+  hipStream_t s = c->stream;
+  PrimAlloc pa{arena_alloc_cb, &c->arena};
+  const unsigned total_cols = c->h_glob->total_cols;
+
+  // ---- column index ---------------------------------------------------------------
+  CK *ck_in, *ck_out;
+  uint32_t *cv_in, *cv_out, *col_first;
+  float4* spt;
+  ALLOC(ck_in, CK, n_vox);
+  ALLOC(ck_out, CK, n_vox);
+  ALLOC(cv_in, uint32_t, n_vox);
+  ALLOC(cv_out, uint32_t, n_vox);
+  ALLOC(col_first, uint32_t, (size_t)total_cols + 1);
+  ALLOC(spt, float4, n_vox);
+  hipLaunchKernelGGL((k_column_keys<CK>), dim3(nblk(n_vox)), dim3(kBlock), 0, s, d_vox, d_vox_frame, c->d_fi,
+                     n_vox, c->inv_xy, c->inv_z, zbits, ck_in, cv_in);
+  if (sizeof(CK) == 4) {
+    HIPCHK(sort_pairs_u32(pa, (const uint32_t*)ck_in, (uint32_t*)ck_out, cv_in, cv_out, n_vox, key2_bits, s));
+  } else {
+    HIPCHK(sort_pairs_u64(pa, (const uint64_t*)ck_in, (uint64_t*)ck_out, cv_in, cv_out, n_vox, key2_bits, s));
+  }
+  hipLaunchKernelGGL((k_column_table<CK>), dim3(nblk((size_t)total_cols + 1)), dim3(kBlock), 0, s, ck_out, n_vox,
+                     total_cols, zbits, col_first);
+  hipLaunchKernelGGL(k_gather_sorted, dim3(nblk(n_vox)), dim3(kBlock), 0, s, d_vox, cv_out, n_vox, spt);
+
+  // ---- A6 normals -----------------------------------------------------------------
+  float4* d_normals;
+  ALLOC(d_normals, float4, n_vox);
+  c->d_normals = d_normals;
+  if (c->normals_cap_small) {
+    hipLaunchKernelGGL((k_normals<CK, 4>), dim3(nblk(n_vox)), dim3(kBlock), 0, s, spt, ck_out, col_first,
+                       d_vox_frame, c->d_fi, n_vox, c->inv_xy, c->inv_z, zbits, c->radius, c->r2, c->ring,
+                       d_normals);
+  } else {
+    hipLaunchKernelGGL((k_normals<CK, 64>), dim3(nblk(n_vox)), dim3(kBlock), 0, s, spt, ck_out, col_first,
+                       d_vox_frame, c->d_fi, n_vox, c->inv_xy, c->inv_z, zbits, c->radius, c->r2, c->ring,
+                       d_normals);
+  }
+
+  // ---- A7 gate + compaction ---------------------------------------------------------
+  uint32_t *flags, *fscan;
+  ALLOC(flags, uint32_t, (size_t)n_vox + 1);
+  ALLOC(fscan, uint32_t, (size_t)n_vox + 1);
+  hipLaunchKernelGGL(k_fit_flags, dim3(nblk((size_t)n_vox + 1)), dim3(kBlock), 0, s, d_normals, n_vox, c->th_norm,
+                     flags);
+  HIPCHK(exclusive_scan_u32(pa, flags, fscan, (size_t)n_vox + 1, s));
+  hipLaunchKernelGGL(k_frame_fit_ranges, dim3(nblk(F)), dim3(kBlock), 0, s, c->d_fi, F, fscan);
+  uint32_t* h_cnt = reinterpret_cast<uint32_t*>(&c->h_glob->pad);
+  HIPCHK(hipMemcpyAsync(h_cnt, fscan + n_vox, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  const unsigned n_fit = *h_cnt;
+  c->n_fit_total = n_fit;
+  int* fit_rank;
+  ALLOC(fit_rank, int, n_vox);
+  uint32_t* fit_idx;
+  float4 *fit_pt, *fit_nrm;
+  int* fit_frame;
+  ALLOC(fit_idx, uint32_t, std::max(n_fit, 1u));
+  ALLOC(fit_pt, float4, std::max(n_fit, 1u));
+  ALLOC(fit_nrm, float4, std::max(n_fit, 1u));
+  ALLOC(fit_frame, int, std::max(n_fit, 1u));
+  c->d_fit_idx = fit_idx;
+  hipLaunchKernelGGL(k_fit_scatter, dim3(nblk(n_vox)), dim3(kBlock), 0, s, flags, fscan, n_vox, d_vox, d_normals,
+                     d_vox_frame, fit_rank, fit_idx, fit_pt, fit_nrm, fit_frame);
+  if (n_fit == 0) return HOPE_OK;
+
+  HIPCHK(hipEventRecord(c->ev_a, s));  // the reference's timer window opens (plane_segment.cpp:157)
+
+  // ---- A8 kNN -----------------------------------------------------------------------
+  int* knn;
+  ALLOC(knn, int, (size_t)n_fit * K);
+  c->d_knn = knn;
+  if (K <= 8) {
+    hipLaunchKernelGGL((k_knn<CK, 8>), dim3(nblk(n_vox)), dim3(kBlock), 0, s, spt, ck_out, col_first, d_vox_frame,
+                       fit_rank, c->d_fi, n_vox, c->inv_xy, c->inv_z, c->cfg.th_xy, zbits, K, knn);
+  } else {
+    hipLaunchKernelGGL((k_knn<CK, kMaxKnn>), dim3(nblk(n_vox)), dim3(kBlock), 0, s, spt, ck_out, col_first,
+                       d_vox_frame, fit_rank, c->d_fi, n_vox, c->inv_xy, c->inv_z, c->cfg.th_xy, zbits, K, knn);
+  }
+
+  // ---- A9 region growing as min-rank reachability -----------------------------------
+  int *rank, *seed_node, *parent, *L, *root, *label;
+  ALLOC(rank, int, n_fit);
+  ALLOC(seed_node, int, n_fit);
+  ALLOC(parent, int, n_fit);
+  ALLOC(L, int, n_fit);
+  ALLOC(root, int, n_fit);
+  ALLOC(label, int, n_fit);
+  const unsigned gb = nblk(n_fit);
+  hipLaunchKernelGGL(k_seed_ranks, dim3(gb), dim3(kBlock), 0, s, c->d_fi, fit_frame, n_fit, rank, seed_node, parent,
+                     L);
+  hipLaunchKernelGGL(k_union_mutual, dim3(gb), dim3(kBlock), 0, s, knn, fit_pt, n_fit, K, c->cfg.th_z, parent);
+  hipLaunchKernelGGL(k_flatten_roots, dim3(gb), dim3(kBlock), 0, s, parent, rank, n_fit, root, L);
+  for (int iter = 0; iter < 100000; ++iter) {
+    HIPCHK(hipMemsetAsync(&c->d_glob->changed, 0, sizeof(unsigned), s));
+    for (int rep = 0; rep < 2; ++rep)
+      hipLaunchKernelGGL(k_label_sweep, dim3(gb), dim3(kBlock), 0, s, knn, fit_pt, root, seed_node, n_fit, K,
+                         c->cfg.th_z, L, &c->d_glob->changed);
+    int st = sync_globals(c);
+    if (st != HOPE_OK) return st;
+    if (!c->h_glob->changed) break;
+  }
+
+  // ---- segments -> clusters (size filter, z_growing.cpp:149-162) ---------------------
+  uint32_t *cnt, *is_seg, *is_cl, *cl_pts, *scan_seg, *scan_cl, *scan_pts;
+  ALLOC(cnt, uint32_t, (size_t)n_fit + 1);
+  ALLOC(is_seg, uint32_t, (size_t)n_fit + 1);
+  ALLOC(is_cl, uint32_t, (size_t)n_fit + 1);
+  ALLOC(cl_pts, uint32_t, (size_t)n_fit + 1);
+  ALLOC(scan_seg, uint32_t, (size_t)n_fit + 1);
+  ALLOC(scan_cl, uint32_t, (size_t)n_fit + 1);
+  ALLOC(scan_pts, uint32_t, (size_t)n_fit + 1);
+  HIPCHK(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * ((size_t)n_fit + 1), s));
+  hipLaunchKernelGGL(k_segment_sizes, dim3(gb), dim3(kBlock), 0, s, root, L, n_fit, label, cnt);
+  hipLaunchKernelGGL(k_segment_flags, dim3(nblk((size_t)n_fit + 1)), dim3(kBlock), 0, s, cnt, n_fit,
+                     c->cfg.min_cluster, is_seg, is_cl, cl_pts);
+  HIPCHK(exclusive_scan_u32(pa, is_seg, scan_seg, (size_t)n_fit + 1, s));
+  HIPCHK(exclusive_scan_u32(pa, is_cl, scan_cl, (size_t)n_fit + 1, s));
+  HIPCHK(exclusive_scan_u32(pa, cl_pts, scan_pts, (size_t)n_fit + 1, s));
+  hipLaunchKernelGGL(k_frame_cluster_ranges, dim3(nblk(F)), dim3(kBlock), 0, s, c->d_fi, F, scan_seg, scan_cl);
+  HIPCHK(hipMemcpyAsync(h_cnt, scan_cl + n_fit, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  const unsigned n_cl = *h_cnt;
+  c->n_cl_total = n_cl;
+
+  int* cid;
+  uint32_t *mkey, *mkey_s, *mval, *members, *cl_first;
+  ClusterRec* rec;
+  ALLOC(cid, int, n_fit);
+  ALLOC(mkey, uint32_t, n_fit);
+  ALLOC(mkey_s, uint32_t, n_fit);
+  ALLOC(mval, uint32_t, n_fit);
+  ALLOC(members, uint32_t, n_fit);
+  ALLOC(cl_first, uint32_t, std::max(n_cl, 1u));
+  ALLOC(rec, ClusterRec, std::max(n_cl, 1u));
+  c->d_cid = cid;
+  c->d_members = members;
+  c->d_cl_first = cl_first;
+  hipLaunchKernelGGL(k_point_clusters, dim3(gb), dim3(kBlock), 0, s, label, is_cl, scan_cl, n_fit, n_cl, cid, mkey,
+                     mval);
+  if (n_cl > 0) {
+    HIPCHK(sort_pairs_u32(pa, mkey, mkey_s, mval, members, n_fit, bits_for(n_cl), s));
+    hipLaunchKernelGGL(k_cluster_heads, dim3(gb), dim3(kBlock), 0, s, cnt, is_cl, scan_cl, scan_pts, seed_node,
+                       fit_frame, c->d_fi, n_fit, cl_first, rec);
+    // ---- A10..A12 -------------------------------------------------------------------
+    hipLaunchKernelGGL(k_cluster_verify, dim3(nblk(n_cl, kWave)), dim3(kWave), 0, s, members, cl_first, fit_pt,
+                       fit_nrm, n_cl, c->th_angle, rec);
+    c->h_rec.resize(n_cl);
+    HIPCHK(hipMemcpyAsync(c->h_rec.data(), rec, sizeof(ClusterRec) * n_cl, hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(hipEventRecord(c->ev_b, s));  // the window closes (plane_segment.cpp:168)
+  return HOPE_OK;
+}
+
+template <class Src>
+int run_pipeline(hope_ctx* c, const Src& src, size_t n_per_frame)
+{
+  const int F = c->n_frames;
+  hipStream_t s = c->stream;
+  const auto t0 = std::chrono::steady_clock::now();
+  c->ref_ms = 0;
+  c->n_vox_total = c->n_fit_total = c->n_cl_total = 0;
+  c->h_rec.clear();
+  c->h_nplanes.assign(F, 0);
+  c->h_max.assign(F, hope_max_plane{});
+  c->d_vox = nullptr;
+  c->d_normals = nullptr;
+  c->d_fit_idx = nullptr;
+  c->d_knn = nullptr;
+  c->d_cid = nullptr;
+  c->d_members = nullptr;
+  c->d_cl_first = nullptr;
+  if ((unsigned long long)n_per_frame * (unsigned long long)F >= 0xffffffffull) {
+    c->err = "input larger than 2^32-1 points per call is not supported";
+    return HOPE_E_RANGE;
+  }
+
+  // per-frame state
+  c->h_fi.assign(F, FrameInfo{});
+  for (int f = 0; f < F; ++f) {
+    FrameInfo& fi = c->h_fi[f];
+    make_affine(c->frame_poses.empty() ? c->pose : c->frame_poses[f], fi.aff);
+    for (int d = 0; d < 3; ++d) {
+      fi.bb_min[d] = 0xffffffffu;
+      fi.bb_max[d] = 0u;
+    }
+  }
+  FrameInfo* d_fi;
+  ALLOC(d_fi, FrameInfo, F);
+  c->d_fi = d_fi;
+  HIPCHK(hipMemcpyAsync(d_fi, c->h_fi.data(), sizeof(FrameInfo) * F, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemsetAsync(c->d_glob, 0, sizeof(Globals), s));
+
+  // ---- A1..A3 + bbox ------------------------------------------------------------------
+  if (n_per_frame > 0) {
+    const unsigned bx = std::max(1u, std::min<unsigned>(nblk(n_per_frame, kBlock * 8), 2048u));
+    hipLaunchKernelGGL((k_bbox<Src>), dim3(bx, F), dim3(kBlock), 0, s, src, d_fi);
+  }
+  hipLaunchKernelGGL(k_frame_grid, dim3(1), dim3(64), 0, s, d_fi, F, c->inv_xy, c->inv_z, c->d_glob);
+  int st = sync_globals(c);
+  if (st != HOPE_OK) return st;
+  if (c->h_glob->any_overflow) {
+    c->err = "VoxelGrid leaf size too small for the input extent (more than INT_MAX cells); "
+             "PCL would pass the cloud through unfiltered, which this library does not support";
+    return HOPE_E_RANGE;
+  }
+
+  // ---- A5 voxel grid ------------------------------------------------------------------
+  const int cell_bits = bits_for(c->h_glob->max_cells - 1);
+  const int total_bits = cell_bits + bits_for((unsigned long long)F);
+  float4* d_vox = nullptr;
+  int* d_vox_frame = nullptr;
+  if (n_per_frame > 0) {
+    if (total_bits <= 32)
+      st = stage_voxel<Src, uint32_t>(c, src, n_per_frame, cell_bits, total_bits, d_vox, d_vox_frame);
+    else
+      st = stage_voxel<Src, uint64_t>(c, src, n_per_frame, cell_bits, total_bits, d_vox, d_vox_frame);
+    if (st != HOPE_OK) return st;
+  }
+  c->d_vox = d_vox;
+
+  // ---- A6..A12 ------------------------------------------------------------------------
+  bool timed = false;
+  if (c->n_vox_total > 0) {
+    const int zbits = bits_for(c->h_glob->max_div_z - 1);
+    const int key2_bits = zbits + bits_for(c->h_glob->total_cols);
+    if (key2_bits <= 32)
+      st = stage_rest<uint32_t>(c, d_vox, d_vox_frame, zbits, key2_bits);
+    else
+      st = stage_rest<uint64_t>(c, d_vox, d_vox_frame, zbits, key2_bits);
+    if (st != HOPE_OK) return st;
+    timed = c->n_fit_total > 0;
+  }
+  HIPCHK(hipMemcpyAsync(c->h_fi.data(), d_fi, sizeof(FrameInfo) * F, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (timed) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev_a, c->ev_b) == hipSuccess) c->ref_ms = ms;
+  }
+  if (c->n_vox_total == 0)
+    for (FrameInfo& fi : c->h_fi) fi.n_vox = fi.n_fit = fi.n_segments = fi.n_clusters = 0;
+  else if (c->n_fit_total == 0)
+    for (FrameInfo& fi : c->h_fi) fi.n_segments = fi.n_clusters = 0;
+  rt_post(c);
+  int worst = HOPE_OK;
+  for (FrameInfo& fi : c->h_fi) {
+    fi.status = fi.n_vox == 0 ? HOPE_EMPTY : (fi.n_fit == 0 ? HOPE_NO_NORMAL_FIT : HOPE_OK);
+    worst = std::max(worst, fi.status);
+  }
+  c->whole_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return worst;
+}
+
+}  // namespace
+
+/* =====================================================================================
+ * C ABI
+ * =================================================================================== */
+extern "C" {
+
+HOPE_API int hope_config_default(hope_config* cfg)
+{
+  if (!cfg) return HOPE_E_INVALID;
+  std::memset(cfg, 0, sizeof(*cfg));
+  cfg->th_xy = 0.05f;
+  cfg->th_z = 0.02f;
+  cfg->min_depth = 0.3f;
+  cfg->max_depth = 8.0f;
+  cfg->fx = 517.0f;
+  cfg->fy = 517.0f;
+  cfg->cx = 318.6f;
+  cfg->cy = 255.3f;
+  cfg->depth_scale = 5000.0f;
+  cfg->knn = 8;
+  cfg->min_cluster = 3;
+  cfg->mode = HOPE_MODE_OFFLINE;
+  cfg->min_height = 0.8f;
+  cfg->max_height = 1.5f;
+  cfg->aggressive_merge = 1;
+  cfg->device = 0;
+  return HOPE_OK;
+}
+
+HOPE_API int hope_create(const hope_config* cfg, hope_ctx** out)
+{
+  if (!cfg || !out) return HOPE_E_INVALID;
+  if (!(cfg->th_xy > 0.f) || !(cfg->th_z > 0.f) || cfg->knn < 1 || cfg->knn > kMaxKnn || cfg->min_cluster < 1)
+    return HOPE_E_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || cfg->device < 0 || cfg->device >= ndev) return HOPE_E_HIP;
+  if (hipSetDevice(cfg->device) != hipSuccess) return HOPE_E_HIP;
+  hope_ctx* c = new hope_ctx();
+  c->cfg = *cfg;
+  derive_thresholds(c);
+  c->pose = Pose{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 1.f}};
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&c->ev_a) != hipSuccess || hipEventCreate(&c->ev_b) != hipSuccess ||
+      hipMalloc((void**)&c->d_glob, sizeof(Globals)) != hipSuccess ||
+      hipHostMalloc((void**)&c->h_glob, sizeof(Globals)) != hipSuccess) {
+    delete c;
+    return HOPE_E_HIP;
+  }
+  const char* knob = std::getenv("HOPE_DEBUG_SMALL_NB_CAP");
+  c->normals_cap_small = (knob && knob[0] == '1') ? 1 : 0;
+  *out = c;
+  return HOPE_OK;
+}
+
+HOPE_API void hope_destroy(hope_ctx* c)
+{
+  if (!c) return;
+  (void)hipSetDevice(c->cfg.device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  c->arena.release();
+  if (c->d_glob) (void)hipFree(c->d_glob);
+  if (c->h_glob) (void)hipHostFree(c->h_glob);
+  if (c->ev_a) (void)hipEventDestroy(c->ev_a);
+  if (c->ev_b) (void)hipEventDestroy(c->ev_b);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+HOPE_API const char* hope_last_error(const hope_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+
+HOPE_API int hope_set_pose(hope_ctx* c, const float t[3], const float q[4])
+{
+  if (!c || !t || !q) return HOPE_E_INVALID;
+  for (int i = 0; i < 3; ++i) c->pose.t[i] = t[i];
+  for (int i = 0; i < 4; ++i) c->pose.q[i] = q[i];
+  c->frame_poses.clear();
+  return HOPE_OK;
+}
+
+HOPE_API int hope_set_frame_poses(hope_ctx* c, int n, const float* t, const float* q)
+{
+  if (!c || n < 0 || (n > 0 && (!t || !q))) return HOPE_E_INVALID;
+  c->frame_poses.resize(n);
+  for (int f = 0; f < n; ++f) {
+    for (int i = 0; i < 3; ++i) c->frame_poses[f].t[i] = t[3 * f + i];
+    for (int i = 0; i < 4; ++i) c->frame_poses[f].q[i] = q[4 * f + i];
+  }
+  return HOPE_OK;
+}
+
+HOPE_API int hope_set_height_window(hope_ctx* c, float mn, float mx)
+{
+  if (!c) return HOPE_E_INVALID;
+  c->cfg.min_height = mn;
+  c->cfg.max_height = mx;
+  return HOPE_OK;
+}
+
+HOPE_API int hope_segment_depth_u16(hope_ctx* c, const uint16_t* depth, int w, int h, int n_frames, int on_device)
+{
+  if (!c) return HOPE_E_INVALID;
+  if (!depth || w <= 0 || h <= 0 || n_frames <= 0) {
+    c->err = "hope_segment_depth_u16: bad argument";
+    return HOPE_E_INVALID;
+  }
+  if (!c->frame_poses.empty() && (int)c->frame_poses.size() != n_frames) {
+    c->err = "frame pose count does not match n_frames";
+    return HOPE_E_INVALID;
+  }
+  HIPCHK(hipSetDevice(c->cfg.device));
+  c->arena.reset();
+  c->n_frames = n_frames;
+  c->src_kind = 1;
+  const size_t ppf = (size_t)w * h;
+  const uint16_t* d_depth = depth;
+  if (!on_device) {
+    uint16_t* buf;
+    ALLOC(buf, uint16_t, ppf * n_frames);
+    HIPCHK(hipMemcpyAsync(buf, depth, sizeof(uint16_t) * ppf * n_frames, hipMemcpyHostToDevice, c->stream));
+    d_depth = buf;
+  }
+  DepthSrc src;
+  src.depth = d_depth;
+  src.w = w;
+  src.h = h;
+  src.ppf = (unsigned)ppf;
+  src.fx = c->cfg.fx;
+  src.fy = c->cfg.fy;
+  src.cx = c->cfg.cx;
+  src.cy = c->cfg.cy;
+  src.scale = c->cfg.depth_scale;
+  src.min_d = c->cfg.min_depth;
+  src.max_d = c->cfg.max_depth;
+  c->dsrc = src;
+  return run_pipeline(c, src, ppf);
+}
+
+HOPE_API int hope_segment_cloud_xyz(hope_ctx* c, const void* xyz, size_t n, size_t stride, int apply, int on_device)
+{
+  if (!c) return HOPE_E_INVALID;
+  if ((!xyz && n > 0) || stride < 12 || (stride % 4) != 0) {
+    c->err = "hope_segment_cloud_xyz: bad argument";
+    return HOPE_E_INVALID;
+  }
+  HIPCHK(hipSetDevice(c->cfg.device));
+  c->arena.reset();
+  c->n_frames = 1;
+  c->src_kind = 2;
+  const void* d_xyz = xyz;
+  if (!on_device && n > 0) {
+    char* buf;
+    ALLOC(buf, char, n * stride);
+    HIPCHK(hipMemcpyAsync(buf, xyz, n * stride, hipMemcpyHostToDevice, c->stream));
+    d_xyz = buf;
+  }
+  std::vector<Pose> saved;
+  saved.swap(c->frame_poses);  // a cloud call always uses the single pose
+  CloudSrc src;
+  src.base = static_cast<const char*>(d_xyz);
+  src.stride = stride;
+  src.n = (unsigned)n;
+  src.apply = apply ? 1 : 0;
+  src.min_d = c->cfg.min_depth;
+  src.max_d = c->cfg.max_depth;
+  c->csrc = src;
+  const int st = run_pipeline(c, src, n);
+  c->frame_poses.swap(saved);
+  return st;
+}
+
+#define GET_FRAME(c, frame)                                   \
+  if (!(c)) return HOPE_E_INVALID;                            \
+  if ((frame) < 0 || (frame) >= (int)(c)->h_fi.size()) {      \
+    (c)->err = "frame index out of range";                    \
+    return HOPE_E_RANGE;                                      \
+  }                                                           \
+  const FrameInfo& F = (c)->h_fi[(frame)];                    \
+  (void)F;
+
+HOPE_API int hope_num_frames(const hope_ctx* c) { return c ? (int)c->h_fi.size() : HOPE_E_INVALID; }
+
+HOPE_API int hope_frame_counts(hope_ctx* c, int frame, hope_counts* out)
+{
+  GET_FRAME(c, frame);
+  if (!out) return HOPE_E_INVALID;
+  std::memset(out, 0, sizeof(*out));
+  out->n_in = c->src_kind == 1 ? (int64_t)c->dsrc.ppf : (int64_t)c->csrc.n;
+  out->n_raw = F.n_raw;
+  out->n_vox = F.n_vox;
+  out->n_fit = F.n_fit;
+  out->n_segments = F.n_segments;
+  out->n_clusters = F.n_clusters;
+  out->n_planes = c->h_nplanes[frame];
+  for (int d = 0; d < 3; ++d) {
+    out->grid[d] = F.div_b[d];
+    out->min_b[d] = F.min_b[d];
+  }
+  out->vox_passthrough = 0;
+  out->status = F.status;
+  return HOPE_OK;
+}
+
+static int copy_out(hope_ctx* c, void* dst, const void* src, size_t bytes)
+{
+  if (bytes == 0) return HOPE_OK;
+  if (!dst || !src) return HOPE_E_INVALID;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return HOPE_OK;
+}
+
+HOPE_API int hope_get_transformed(hope_ctx* c, int frame, float* xyz, int32_t* src_index)
+{
+  GET_FRAME(c, frame);
+  if (!xyz || !src_index) return HOPE_E_INVALID;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  const size_t n = c->src_kind == 1 ? c->dsrc.ppf : c->csrc.n;
+  if (n == 0 || F.n_raw == 0) return HOPE_OK;
+  hipStream_t s = c->stream;
+  PrimAlloc pa{arena_alloc_cb, &c->arena};
+  uint32_t *flags, *scan;
+  float* d_xyz;
+  int* d_src;
+  ALLOC(flags, uint32_t, n + 1);
+  ALLOC(scan, uint32_t, n + 1);
+  ALLOC(d_xyz, float, (size_t)F.n_raw * 3);
+  ALLOC(d_src, int, F.n_raw);
+  if (c->src_kind == 1) {
+    hipLaunchKernelGGL((k_valid_flags<DepthSrc>), dim3(nblk(n + 1)), dim3(kBlock), 0, s, c->dsrc, c->d_fi, frame,
+                       flags);
+    HIPCHK(exclusive_scan_u32(pa, flags, scan, n + 1, s));
+    hipLaunchKernelGGL((k_export_transformed<DepthSrc>), dim3(nblk(n)), dim3(kBlock), 0, s, c->dsrc, c->d_fi, frame,
+                       scan, d_xyz, d_src);
+  } else {
+    hipLaunchKernelGGL((k_valid_flags<CloudSrc>), dim3(nblk(n + 1)), dim3(kBlock), 0, s, c->csrc, c->d_fi, frame,
+                       flags);
+    HIPCHK(exclusive_scan_u32(pa, flags, scan, n + 1, s));
+    hipLaunchKernelGGL((k_export_transformed<CloudSrc>), dim3(nblk(n)), dim3(kBlock), 0, s, c->csrc, c->d_fi, frame,
+                       scan, d_xyz, d_src);
+  }
+  int st = copy_out(c, xyz, d_xyz, sizeof(float) * 3 * (size_t)F.n_raw);
+  if (st != HOPE_OK) return st;
+  return copy_out(c, src_index, d_src, sizeof(int) * (size_t)F.n_raw);
+}
+
+HOPE_API int hope_get_downsampled(hope_ctx* c, int frame, float* xyz)
+{
+  GET_FRAME(c, frame);
+  if (F.n_vox == 0) return HOPE_OK;
+  if (!xyz) return HOPE_E_INVALID;
+  std::vector<float4> tmp(F.n_vox);
+  int st = copy_out(c, tmp.data(), c->d_vox + F.vox_start, sizeof(float4) * (size_t)F.n_vox);
+  if (st != HOPE_OK) return st;
+  for (int i = 0; i < F.n_vox; ++i) {
+    xyz[3 * i] = tmp[i].x;
+    xyz[3 * i + 1] = tmp[i].y;
+    xyz[3 * i + 2] = tmp[i].z;
+  }
+  return HOPE_OK;
+}
+
+HOPE_API int hope_get_normals(hope_ctx* c, int frame, float* nxyzc)
+{
+  GET_FRAME(c, frame);
+  if (F.n_vox == 0) return HOPE_OK;
+  return copy_out(c, nxyzc, c->d_normals + F.vox_start, sizeof(float4) * (size_t)F.n_vox);
+}
+
+HOPE_API int hope_get_fit_indices(hope_ctx* c, int frame, int32_t* idx)
+{
+  GET_FRAME(c, frame);
+  if (F.n_fit == 0) return HOPE_OK;
+  int st = copy_out(c, idx, c->d_fit_idx + F.fit_start, sizeof(int32_t) * (size_t)F.n_fit);
+  if (st != HOPE_OK) return st;
+  for (int i = 0; i < F.n_fit; ++i) idx[i] -= F.vox_start;
+  return HOPE_OK;
+}
+
+HOPE_API int hope_get_knn(hope_ctx* c, int frame, int32_t* nbr)
+{
+  GET_FRAME(c, frame);
+  if (F.n_fit == 0) return HOPE_OK;
+  const size_t cnt = (size_t)F.n_fit * c->cfg.knn;
+  int st = copy_out(c, nbr, c->d_knn + (size_t)F.fit_start * c->cfg.knn, sizeof(int32_t) * cnt);
+  if (st != HOPE_OK) return st;
+  for (size_t i = 0; i < cnt; ++i)
+    if (nbr[i] >= 0) nbr[i] -= F.fit_start;
+  return HOPE_OK;
+}
+
+HOPE_API int hope_get_labels(hope_ctx* c, int frame, int32_t* labels)
+{
+  GET_FRAME(c, frame);
+  if (F.n_fit == 0) return HOPE_OK;
+  int st = copy_out(c, labels, c->d_cid + F.fit_start, sizeof(int32_t) * (size_t)F.n_fit);
+  if (st != HOPE_OK) return st;
+  for (int i = 0; i < F.n_fit; ++i)
+    if (labels[i] >= 0) labels[i] -= F.cl_start;
+  return HOPE_OK;
+}
+
+HOPE_API int hope_get_clusters(hope_ctx* c, int frame, hope_cluster* out, int cap)
+{
+  GET_FRAME(c, frame);
+  if (!out && cap > 0) return HOPE_E_INVALID;
+  const int n = std::min(cap, F.n_clusters);
+  if (n > 0) std::memcpy(out, c->h_rec.data() + F.cl_start, sizeof(hope_cluster) * (size_t)n);
+  return n;
+}
+
+HOPE_API int hope_get_cluster_indices(hope_ctx* c, int frame, int cluster, int32_t* idx, int cap)
+{
+  GET_FRAME(c, frame);
+  if (cluster < 0 || cluster >= F.n_clusters) return HOPE_E_RANGE;
+  const ClusterRec& r = c->h_rec[F.cl_start + cluster];
+  if (r.size > cap || !idx) return HOPE_E_RANGE;
+  uint32_t first = 0;
+  int st = copy_out(c, &first, c->d_cl_first + F.cl_start + cluster, sizeof(uint32_t));
+  if (st != HOPE_OK) return st;
+  st = copy_out(c, idx, c->d_members + first, sizeof(int32_t) * (size_t)r.size);
+  if (st != HOPE_OK) return st;
+  for (int i = 0; i < r.size; ++i) idx[i] -= F.fit_start;
+  return r.size;
+}
+
+HOPE_API int hope_get_max_plane(hope_ctx* c, int frame, hope_max_plane* out)
+{
+  GET_FRAME(c, frame);
+  if (!out) return HOPE_E_INVALID;
+  *out = c->h_max[frame];
+  return HOPE_OK;
+}
+
+HOPE_API int hope_last_timing(hope_ctx* c, double* whole_ms, double* ref_ms)
+{
+  if (!c) return HOPE_E_INVALID;
+  if (whole_ms) *whole_ms = c->whole_ms;
+  if (ref_ms) *ref_ms = c->ref_ms;
+  return HOPE_OK;
+}
+
+}  // extern "C"

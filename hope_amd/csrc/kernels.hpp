@@ -1,0 +1,1121 @@
+// kernels.hpp — HIP kernels of the HoPE PlaneSegment hot path for gfx950 (MI355X).
+//
+// Everything here is HBM/L2-bound integer and fp32 work: no MFMA.
+// Arithmetic that feeds a discontinuous decision (voxel index, |nz| gate, dz gate,
+// normalAnalysis thresholds) uses only IEEE + - * / sqrt in a fixed order, and this
+// translation unit is compiled with -ffp-contract=off, so results are bit-identical to
+// the scalar CPU statement of the reference.  Reference citations (file:line, relative
+// to DrawZeroPoint/hope) are given per kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "../../include/hope_detmath.h"
+#include "../../include/hope_gpu.h"
+
+namespace hope {
+
+constexpr int kBlock = 256;
+constexpr int kWave = 64;
+constexpr int kMaxKnn = 32;
+
+// Per-frame state, resident in HBM for the whole call (one per depth frame / cloud).
+struct FrameInfo {
+  float aff[12];        // rotation r[9] row-major + translation t[3]   (A3)
+  unsigned bb_min[3];   // order-preserving encodings of the bbox        (A5 getMinMax3D)
+  unsigned bb_max[3];
+  int n_raw;            // points that survive A1/A2
+  int min_b[3];         // VoxelGrid min_b_                              (A5)
+  int div_b[3];         // VoxelGrid div_b_
+  int overflow;         // dx*dy*dz > INT_MAX (PCL copies the input through)
+  long long cells;      // div_b product
+  float slack;          // float-rounding slack of a column index, in cells (kNN bound)
+  int col_off;          // first entry of this frame in the column table
+  int vox_start, n_vox; // range in the global down-sampled arrays
+  int fit_start, n_fit; // range in the global normal-filtered arrays
+  int seg_start, n_segments;
+  int cl_start, n_clusters;
+  int status;
+};
+
+struct Globals {  // scalars produced on device, read back at the sync points
+  unsigned long long max_cells;
+  unsigned int total_cols;
+  unsigned int max_div_z;
+  unsigned int any_overflow;
+  unsigned int n_runs;
+  unsigned int changed;
+  unsigned int n_vox_total;
+  unsigned int pad;
+};
+
+struct DepthSrc {
+  const uint16_t* depth;
+  int w, h;
+  unsigned ppf;  // pixels per frame
+  float fx, fy, cx, cy, scale, min_d, max_d;
+};
+
+struct CloudSrc {
+  const char* base;
+  unsigned long long stride;
+  unsigned n;
+  int apply;  // 1: PassThrough z in [min_d, max_d] + pose transform
+  float min_d, max_d;
+};
+
+// ---- small device helpers ------------------------------------------------------------
+__device__ __forceinline__ unsigned f2ord(float f)
+{
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned u)
+{
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+__device__ __forceinline__ bool finite3(float x, float y, float z)
+{
+  return isfinite(x) && isfinite(y) && isfinite(z);
+}
+
+// A3: Eigen Affine3f * Vector3f = t + (r0*x + (r1*y + r2*z))   (transform.cpp:168-185)
+__device__ __forceinline__ void apply_affine(const float* a, float x, float y, float z, float& ox, float& oy,
+                                             float& oz)
+{
+  ox = a[9] + (a[0] * x + (a[1] * y + a[2] * z));
+  oy = a[10] + (a[3] * x + (a[4] * y + a[5] * z));
+  oz = a[11] + (a[6] * x + (a[7] * y + a[8] * z));
+}
+
+// A1 + A2 + A3 for one pixel of a TUM-style depth frame (get_cloud.cpp:220-233,
+// utilities.cpp:662-675, transform.cpp:152-191).  Returns false for a dropped pixel.
+__device__ __forceinline__ bool load_point(const DepthSrc& s, const FrameInfo* fi, int frame, unsigned pix,
+                                           float& ox, float& oy, float& oz)
+{
+  const uint16_t d = s.depth[(size_t)frame * s.ppf + pix];
+  const int col = (int)(pix % (unsigned)s.w);
+  const int row = (int)(pix / (unsigned)s.w);
+  const float z = (float)d / s.scale;
+  if (!(z < s.max_d && z > s.min_d)) return false;
+  const float x = ((float)col - s.cx) * z / s.fx;
+  const float y = ((float)row - s.cy) * z / s.fy;
+  apply_affine(fi[frame].aff, x, y, z, ox, oy, oz);
+  return true;
+}
+
+// A2 + A3 for one record of a point cloud (plane_segment.cpp:118-127,791-795)
+__device__ __forceinline__ bool load_point(const CloudSrc& s, const FrameInfo* fi, int frame, unsigned i,
+                                           float& ox, float& oy, float& oz)
+{
+  const float* p = reinterpret_cast<const float*>(s.base + (size_t)i * s.stride);
+  const float x = p[0], y = p[1], z = p[2];
+  if (!finite3(x, y, z)) return false;
+  if (s.apply) {
+    if (z < s.min_d || z > s.max_d) return false;
+    apply_affine(fi[frame].aff, x, y, z, ox, oy, oz);
+    return finite3(ox, oy, oz);
+  }
+  ox = x;
+  oy = y;
+  oz = z;
+  return true;
+}
+
+__device__ __forceinline__ unsigned src_count(const DepthSrc& s) { return s.ppf; }
+__device__ __forceinline__ unsigned src_count(const CloudSrc& s) { return s.n; }
+
+// ---- K1: bbox + count per frame ------------------------------------------------------
+// pcl::getMinMax3D inside VoxelGrid::applyFilter.  grid = (blocks, n_frames).
+template <class Src>
+__global__ void __launch_bounds__(kBlock) k_bbox(Src src, FrameInfo* fi)
+{
+  const int frame = blockIdx.y;
+  const unsigned n = src_count(src);
+  float mn[3] = {INFINITY, INFINITY, INFINITY};
+  float mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  int cnt = 0;
+  for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    float x, y, z;
+    if (load_point(src, fi, frame, i, x, y, z)) {
+      mn[0] = fminf(mn[0], x);
+      mn[1] = fminf(mn[1], y);
+      mn[2] = fminf(mn[2], z);
+      mx[0] = fmaxf(mx[0], x);
+      mx[1] = fmaxf(mx[1], y);
+      mx[2] = fmaxf(mx[2], z);
+      ++cnt;
+    }
+  }
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      mn[d] = fminf(mn[d], __shfl_down(mn[d], off));
+      mx[d] = fmaxf(mx[d], __shfl_down(mx[d], off));
+    }
+    cnt += __shfl_down(cnt, off);
+  }
+  __shared__ float s_mn[kBlock / kWave][3], s_mx[kBlock / kWave][3];
+  __shared__ int s_cnt[kBlock / kWave];
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  if (lane == 0) {
+    for (int d = 0; d < 3; ++d) {
+      s_mn[wv][d] = mn[d];
+      s_mx[wv][d] = mx[d];
+    }
+    s_cnt[wv] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kBlock / kWave; ++w) {
+      for (int d = 0; d < 3; ++d) {
+        mn[d] = fminf(mn[d], s_mn[w][d]);
+        mx[d] = fmaxf(mx[d], s_mx[w][d]);
+      }
+      cnt += s_cnt[w];
+    }
+    if (cnt > 0) {
+      for (int d = 0; d < 3; ++d) {
+        atomicMin(&fi[frame].bb_min[d], f2ord(mn[d]));
+        atomicMax(&fi[frame].bb_max[d], f2ord(mx[d]));
+      }
+      atomicAdd(&fi[frame].n_raw, cnt);
+    }
+  }
+}
+
+// ---- K2: VoxelGrid grid set-up per frame (PCL 1.8.1 voxel_grid.hpp applyFilter) -------
+__global__ void k_frame_grid(FrameInfo* fi, int n_frames, float inv_xy, float inv_z, Globals* g)
+{
+  // one thread: the per-frame prefix over column-table sizes is sequential and tiny
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  unsigned col_off = 0;
+  unsigned long long max_cells = 1;
+  unsigned max_dz = 1, any_over = 0;
+  for (int f = 0; f < n_frames; ++f) {
+    FrameInfo& F = fi[f];
+    F.col_off = (int)col_off;
+    F.overflow = 0;
+    F.cells = 0;
+    F.slack = 0.f;
+    for (int d = 0; d < 3; ++d) F.min_b[d] = F.div_b[d] = 0;
+    if (F.n_raw <= 0) {
+      col_off += 1;
+      continue;
+    }
+    const float inv[3] = {inv_xy, inv_xy, inv_z};
+    long long dxyz = 1;
+    float maxabs = 0.f;
+    for (int d = 0; d < 3; ++d) {
+      const float mn = ord2f(F.bb_min[d]), mx = ord2f(F.bb_max[d]);
+      dxyz *= (long long)((mx - mn) * inv[d]) + 1;
+      F.min_b[d] = (int)floorf(mn * inv[d]);
+      const int max_b = (int)floorf(mx * inv[d]);
+      F.div_b[d] = max_b - F.min_b[d] + 1;
+      if (d < 2) maxabs = fmaxf(maxabs, fmaxf(fabsf(mn), fabsf(mx)) * inv[d]);
+    }
+    if (dxyz > 2147483647LL) {
+      F.overflow = 1;
+      any_over = 1;
+      col_off += 1;
+      continue;
+    }
+    F.cells = (long long)F.div_b[0] * F.div_b[1] * F.div_b[2];
+    // |fl(x*inv) - x*inv| <= 2^-24 * |x*inv|; two such errors enter a column difference
+    F.slack = maxabs * 2.4e-7f + 1e-6f;
+    if ((unsigned long long)F.cells > max_cells) max_cells = (unsigned long long)F.cells;
+    if ((unsigned)F.div_b[2] > max_dz) max_dz = (unsigned)F.div_b[2];
+    col_off += (unsigned)(F.div_b[0] * F.div_b[1]) + 1u;
+  }
+  g->max_cells = max_cells;
+  g->total_cols = col_off;
+  g->max_div_z = max_dz;
+  g->any_overflow = any_over;
+}
+
+// ---- K3: voxel keys -------------------------------------------------------------------
+// key = frame << cell_bits | idx, idx = i + j*div_x + k*div_x*div_y with
+// ijk = (int)(floor(p*inv) - (float)min_b)   (voxel_grid.hpp, second pass)
+template <class Src, class KeyT>
+__global__ void __launch_bounds__(kBlock)
+k_voxel_keys(Src src, const FrameInfo* fi, float inv_xy, float inv_z, int cell_bits, int n_frames, KeyT* keys,
+             uint32_t* vals)
+{
+  const int frame = blockIdx.y;
+  const unsigned n = src_count(src);
+  const FrameInfo& F = fi[frame];
+  for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    float x, y, z;
+    KeyT key = (KeyT)n_frames << cell_bits;  // sentinel: sorts behind every frame
+    if (!F.overflow && load_point(src, fi, frame, i, x, y, z)) {
+      const int i0 = (int)(floorf(x * inv_xy) - (float)F.min_b[0]);
+      const int i1 = (int)(floorf(y * inv_xy) - (float)F.min_b[1]);
+      const int i2 = (int)(floorf(z * inv_z) - (float)F.min_b[2]);
+      const int idx = i0 + i1 * F.div_b[0] + i2 * (F.div_b[0] * F.div_b[1]);
+      key = ((KeyT)frame << cell_bits) | (KeyT)(unsigned)idx;
+    }
+    const size_t o = (size_t)frame * n + i;
+    keys[o] = key;
+    vals[o] = (uint32_t)o;
+  }
+}
+
+// first voxel of each frame = lower_bound over the unique keys
+template <class KeyT>
+__global__ void k_frame_vox_ranges(FrameInfo* fi, int n_frames, const KeyT* unique, const unsigned* n_runs_p,
+                                   int cell_bits, Globals* g)
+{
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f > n_frames) return;
+  const unsigned n_runs = *n_runs_p;
+  const KeyT target = (KeyT)f << cell_bits;
+  unsigned lo = 0, hi = n_runs;
+  while (lo < hi) {
+    const unsigned mid = (lo + hi) >> 1;
+    if (unique[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  if (f == n_frames) {
+    g->n_vox_total = lo;
+  } else {
+    fi[f].vox_start = (int)lo;
+  }
+}
+
+__global__ void k_frame_vox_counts(FrameInfo* fi, int n_frames, const Globals* g)
+{
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n_frames) return;
+  const int next = (f + 1 < n_frames) ? fi[f + 1].vox_start : (int)g->n_vox_total;
+  fi[f].n_vox = next - fi[f].vox_start;
+}
+
+// ---- K5: voxel centroids (CentroidPoint<PointXYZ>: sequential float sum / n) -----------
+// One thread per voxel walks its points in ascending source index (the stable sort keeps
+// them so) and re-derives each point from the source instead of re-reading 12 B/pt.
+template <class Src, class KeyT>
+__global__ void __launch_bounds__(kBlock)
+k_centroids(Src src, const FrameInfo* fi, const KeyT* unique, const uint32_t* run_start, const uint32_t* run_count,
+            const uint32_t* vals_sorted, unsigned n_vox, int cell_bits, float4* vox, int* vox_frame)
+{
+  const unsigned v = blockIdx.x * kBlock + threadIdx.x;
+  if (v >= n_vox) return;
+  const int frame = (int)(unique[v] >> cell_bits);
+  const unsigned start = run_start[v], cnt = run_count[v];
+  const unsigned n = src_count(src);
+  const size_t base = (size_t)frame * n;
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  for (unsigned j = 0; j < cnt; ++j) {
+    const unsigned i = (unsigned)(vals_sorted[start + j] - base);
+    float x, y, z;
+    load_point(src, fi, frame, i, x, y, z);
+    sx += x;
+    sy += y;
+    sz += z;
+  }
+  const float c = (float)cnt;
+  vox[v] = make_float4(sx / c, sy / c, sz / c, 0.f);
+  vox_frame[v] = frame;
+}
+
+// ---- column index over the down-sampled cloud -----------------------------------------
+// Index function (any monotone function is exact, it only steers the search):
+// col = clamp(floor(x*inv) - min_b), cz likewise; key2 = (col_off + cy*div_x + cx) << zbits | cz
+__device__ __forceinline__ int cell_unclamped(float x, float inv, int min_b)
+{
+  return (int)(floorf(x * inv) - (float)min_b);
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+template <class KeyT>
+__global__ void __launch_bounds__(kBlock)
+k_column_keys(const float4* vox, const int* vox_frame, const FrameInfo* fi, unsigned n_vox, float inv_xy,
+              float inv_z, int zbits, KeyT* keys, uint32_t* vals)
+{
+  const unsigned v = blockIdx.x * kBlock + threadIdx.x;
+  if (v >= n_vox) return;
+  const FrameInfo& F = fi[vox_frame[v]];
+  const float4 p = vox[v];
+  const int cx = clampi(cell_unclamped(p.x, inv_xy, F.min_b[0]), 0, F.div_b[0] - 1);
+  const int cy = clampi(cell_unclamped(p.y, inv_xy, F.min_b[1]), 0, F.div_b[1] - 1);
+  const int cz = clampi(cell_unclamped(p.z, inv_z, F.min_b[2]), 0, F.div_b[2] - 1);
+  const unsigned col = (unsigned)F.col_off + (unsigned)(cy * F.div_b[0] + cx);
+  keys[v] = ((KeyT)col << zbits) | (KeyT)(unsigned)cz;
+  vals[v] = v;
+}
+
+template <class KeyT>
+__global__ void __launch_bounds__(kBlock)
+k_column_table(const KeyT* skeys, unsigned n_vox, unsigned total_cols, int zbits, uint32_t* col_first)
+{
+  const unsigned c = blockIdx.x * kBlock + threadIdx.x;
+  if (c > total_cols) return;
+  const KeyT target = (KeyT)c << zbits;
+  unsigned lo = 0, hi = n_vox;
+  while (lo < hi) {
+    const unsigned mid = (lo + hi) >> 1;
+    if (skeys[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  col_first[c] = lo;
+}
+
+// sorted copy: xyz + original (PCL-order) index in .w
+__global__ void __launch_bounds__(kBlock)
+k_gather_sorted(const float4* vox, const uint32_t* svals, unsigned n_vox, float4* spt)
+{
+  const unsigned s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= n_vox) return;
+  const uint32_t v = svals[s];
+  float4 p = vox[v];
+  p.w = __uint_as_float(v);
+  spt[s] = p;
+}
+
+// FLANN L2_Simple<float>: ((dx*dx + dy*dy) + dz*dz)
+__device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, float by, float bz)
+{
+  const float dx = ax - bx, dy = ay - by, dz = az - bz;
+  return (dx * dx + dy * dy) + dz * dz;
+}
+
+__device__ __forceinline__ bool di_less(float d1, unsigned i1, float d2, unsigned i2)
+{
+  return d1 < d2 || (d1 == d2 && i1 < i2);
+}
+
+// ---- pcl::computeRoots2 / computeRoots / eigen33 (PCL 1.8.1 common/impl/eigen.hpp) -----
+__device__ inline void compute_roots2(float b, float c, float* roots)
+{
+  roots[0] = 0.f;
+  float d = (float)((double)(b * b) - 4.0 * (double)c);
+  if (d < 0.0) d = 0.0;
+  const float sd = (float)__builtin_sqrt((double)d);
+  roots[2] = 0.5f * (b + sd);
+  roots[1] = 0.5f * (b - sd);
+}
+
+__device__ inline void swapf(float& a, float& b)
+{
+  const float t = a;
+  a = b;
+  b = t;
+}
+
+__device__ inline void compute_roots(const float* m, float* roots)
+{
+  const float m00 = m[0], m01 = m[1], m02 = m[2], m11 = m[4], m12 = m[5], m22 = m[8];
+  const float c0 = m00 * m11 * m22 + 2.f * m01 * m02 * m12 - m00 * m12 * m12 - m11 * m02 * m02 -
+                   m22 * m01 * m01;
+  const float c1 = m00 * m11 - m01 * m01 + m00 * m22 - m02 * m02 + m11 * m22 - m12 * m12;
+  const float c2 = m00 + m11 + m22;
+  if (fabsf(c0) < 1.1920928955078125e-7f) {
+    compute_roots2(c2, c1, roots);
+    return;
+  }
+  const float s_inv3 = (float)(1.0 / 3.0);
+  const float s_sqrt3 = __builtin_sqrtf(3.0f);
+  const float c2_over_3 = c2 * s_inv3;
+  float a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
+  if (a_over_3 > 0.f) a_over_3 = 0.f;
+  const float half_b = 0.5f * (c0 + c2_over_3 * (2.f * c2_over_3 * c2_over_3 - c1));
+  float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
+  if (q > 0.f) q = 0.f;
+  const float rho = __builtin_sqrtf(-a_over_3);
+  const float theta = hope_det_atan2f(__builtin_sqrtf(-q), half_b) * s_inv3;
+  const float cos_theta = hope_det_cosf(theta);
+  const float sin_theta = hope_det_sinf(theta);
+  roots[0] = c2_over_3 + 2.f * rho * cos_theta;
+  roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
+  roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
+  if (roots[0] >= roots[1]) swapf(roots[0], roots[1]);
+  if (roots[1] >= roots[2]) {
+    swapf(roots[1], roots[2]);
+    if (roots[0] >= roots[1]) swapf(roots[0], roots[1]);
+  }
+  if (roots[0] <= 0.f) compute_roots2(c2, c1, roots);
+}
+
+__device__ inline float sqnorm3(const float* v) { return v[0] * v[0] + (v[1] * v[1] + v[2] * v[2]); }
+
+__device__ inline void cross3(const float* a, const float* b, float* o)
+{
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+__device__ inline void eigen33_smallest(const float* mat, float& eigenvalue, float* evec)
+{
+  float scale = 0.f;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) scale = fmaxf(scale, fabsf(mat[i]));
+  if (scale <= 1.17549435e-38f) scale = 1.f;
+  float sm[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) sm[i] = mat[i] / scale;
+  float ev[3];
+  compute_roots(sm, ev);
+  eigenvalue = ev[0] * scale;
+  sm[0] -= ev[0];
+  sm[4] -= ev[0];
+  sm[8] -= ev[0];
+  float v1[3], v2[3], v3[3];
+  cross3(sm + 0, sm + 3, v1);
+  cross3(sm + 0, sm + 6, v2);
+  cross3(sm + 3, sm + 6, v3);
+  const float l1 = sqnorm3(v1), l2 = sqnorm3(v2), l3 = sqnorm3(v3);
+  float vx, vy, vz, l;
+  if (l1 >= l2 && l1 >= l3) {
+    vx = v1[0]; vy = v1[1]; vz = v1[2]; l = l1;
+  } else if (l2 >= l1 && l2 >= l3) {
+    vx = v2[0]; vy = v2[1]; vz = v2[2]; l = l2;
+  } else {
+    vx = v3[0]; vy = v3[1]; vz = v3[2]; l = l3;
+  }
+  const float s = __builtin_sqrtf(l);
+  evec[0] = vx / s;
+  evec[1] = vy / s;
+  evec[2] = vz / s;
+}
+
+// ---- K6: normals (pcl::NormalEstimation radius search + computePointNormal) ------------
+// utilities.cpp:428-446; neighbours within dist2 < r2, accumulated in (dist2, index)
+// order.  One thread per down-sampled point, walking the 5x5 column stencil.
+struct Nb {
+  float d2;
+  unsigned idx;   // PCL-order index (tie-break)
+  unsigned spos;  // position in the sorted copy
+};
+
+template <class KeyT, int CAP>
+__global__ void __launch_bounds__(kBlock)
+k_normals(const float4* spt, const KeyT* skeys, const uint32_t* col_first, const int* vox_frame,
+          const FrameInfo* fi, unsigned n_vox, float inv_xy, float inv_z, int zbits, float radius, float r2,
+          int ring, float4* normals)
+{
+  const unsigned s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= n_vox) return;
+  const float4 q = spt[s];
+  const unsigned qv = __float_as_uint(q.w);
+  const FrameInfo& F = fi[vox_frame[qv]];
+  const int cqx = clampi(cell_unclamped(q.x, inv_xy, F.min_b[0]), 0, F.div_b[0] - 1);
+  const int cqy = clampi(cell_unclamped(q.y, inv_xy, F.min_b[1]), 0, F.div_b[1] - 1);
+  const int czlo = clampi(cell_unclamped(q.z - radius, inv_z, F.min_b[2]) - 1, 0, F.div_b[2] - 1);
+  const int czhi = clampi(cell_unclamped(q.z + radius, inv_z, F.min_b[2]) + 1, 0, F.div_b[2] - 1);
+  const int x0 = max(cqx - ring, 0), x1 = min(cqx + ring, F.div_b[0] - 1);
+  const int y0 = max(cqy - ring, 0), y1 = min(cqy + ring, F.div_b[1] - 1);
+
+  Nb nb[CAP];
+  int total = 0;
+  for (int cy = y0; cy <= y1; ++cy) {
+    for (int cx = x0; cx <= x1; ++cx) {
+      const unsigned col = (unsigned)F.col_off + (unsigned)(cy * F.div_b[0] + cx);
+      unsigned lo = col_first[col];
+      const unsigned end = col_first[col + 1];
+      const KeyT klo = ((KeyT)col << zbits) | (KeyT)(unsigned)czlo;
+      const KeyT khi = ((KeyT)col << zbits) | (KeyT)(unsigned)czhi;
+      unsigned hi = end;
+      while (lo < hi) {  // first entry with key >= klo
+        const unsigned mid = (lo + hi) >> 1;
+        if (skeys[mid] < klo) lo = mid + 1; else hi = mid;
+      }
+      for (unsigned e = lo; e < end && skeys[e] <= khi; ++e) {
+        const float4 p = spt[e];
+        const float d = dist2(q.x, q.y, q.z, p.x, p.y, p.z);
+        if (d < r2) {
+          if (total < CAP) {
+            nb[total].d2 = d;
+            nb[total].idx = __float_as_uint(p.w);
+            nb[total].spos = e;
+          }
+          ++total;
+        }
+      }
+    }
+  }
+  float4 out = make_float4(NAN, NAN, NAN, NAN);
+  if (total >= 3) {
+    float accu[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (total <= CAP) {
+      // insertion sort by (d2, idx), then the single-pass accumulation of
+      // computeMeanAndCovarianceMatrix (PCL 1.8.1 centroid.hpp, float, dense branch)
+      for (int i = 1; i < total; ++i) {
+        const Nb t = nb[i];
+        int j = i - 1;
+        while (j >= 0 && di_less(t.d2, t.idx, nb[j].d2, nb[j].idx)) {
+          nb[j + 1] = nb[j];
+          --j;
+        }
+        nb[j + 1] = t;
+      }
+      for (int i = 0; i < total; ++i) {
+        const float4 p = spt[nb[i].spos];
+        accu[0] += p.x * p.x;
+        accu[1] += p.x * p.y;
+        accu[2] += p.x * p.z;
+        accu[3] += p.y * p.y;
+        accu[4] += p.y * p.z;
+        accu[5] += p.z * p.z;
+        accu[6] += p.x;
+        accu[7] += p.y;
+        accu[8] += p.z;
+      }
+    } else {
+      // more neighbours than the register list holds: selection by repeated scans
+      float last_d = -1.f;
+      unsigned last_i = 0;
+      for (int t = 0; t < total; ++t) {
+        float best_d = INFINITY;
+        unsigned best_i = 0xffffffffu, best_e = 0;
+        for (int cy = y0; cy <= y1; ++cy) {
+          for (int cx = x0; cx <= x1; ++cx) {
+            const unsigned col = (unsigned)F.col_off + (unsigned)(cy * F.div_b[0] + cx);
+            const unsigned end = col_first[col + 1];
+            const KeyT khi = ((KeyT)col << zbits) | (KeyT)(unsigned)czhi;
+            for (unsigned e = col_first[col]; e < end && skeys[e] <= khi; ++e) {
+              const float4 p = spt[e];
+              const float d = dist2(q.x, q.y, q.z, p.x, p.y, p.z);
+              const unsigned pi = __float_as_uint(p.w);
+              if (d < r2 && (t == 0 || di_less(last_d, last_i, d, pi)) && di_less(d, pi, best_d, best_i)) {
+                best_d = d;
+                best_i = pi;
+                best_e = e;
+              }
+            }
+          }
+        }
+        const float4 p = spt[best_e];
+        accu[0] += p.x * p.x;
+        accu[1] += p.x * p.y;
+        accu[2] += p.x * p.z;
+        accu[3] += p.y * p.y;
+        accu[4] += p.y * p.z;
+        accu[5] += p.z * p.z;
+        accu[6] += p.x;
+        accu[7] += p.y;
+        accu[8] += p.z;
+        last_d = best_d;
+        last_i = best_i;
+      }
+    }
+    const float cnt = (float)total;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) accu[k] /= cnt;
+    float cov[9];
+    cov[0] = accu[0] - accu[6] * accu[6];
+    cov[1] = accu[1] - accu[6] * accu[7];
+    cov[2] = accu[2] - accu[6] * accu[8];
+    cov[4] = accu[3] - accu[7] * accu[7];
+    cov[5] = accu[4] - accu[7] * accu[8];
+    cov[8] = accu[5] - accu[8] * accu[8];
+    cov[3] = cov[1];
+    cov[6] = cov[2];
+    cov[7] = cov[5];
+    float eval, evec[3];
+    eigen33_smallest(cov, eval, evec);
+    float nx = evec[0], ny = evec[1], nz = evec[2];
+    const float eig_sum = cov[0] + cov[4] + cov[8];
+    float curvature = 0.f;
+    if (eig_sum != 0.f) curvature = fabsf(eval / eig_sum);
+    // flipNormalTowardsViewpoint(point, 0, 0, 0, ...)   (PCL 1.8.1 normal_3d.h)
+    const float vpx = 0.f - q.x, vpy = 0.f - q.y, vpz = 0.f - q.z;
+    const float cos_theta = (vpx * nx + vpy * ny + vpz * nz);
+    if (cos_theta < 0.f) {
+      nx *= -1.f;
+      ny *= -1.f;
+      nz *= -1.f;
+    }
+    out = make_float4(nx, ny, nz, curvature);
+  }
+  normals[qv] = out;
+}
+
+// ---- K7: |nz| > th_norm gate (utilities.cpp:629-645) + order-preserving compaction -----
+__global__ void __launch_bounds__(kBlock)
+k_fit_flags(const float4* normals, unsigned n_vox, float th_norm, uint32_t* flags)
+{
+  const unsigned v = blockIdx.x * kBlock + threadIdx.x;
+  if (v > n_vox) return;
+  flags[v] = (v < n_vox && fabsf(normals[v].z) > th_norm) ? 1u : 0u;  // NaN fails
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_fit_scatter(const uint32_t* flags, const uint32_t* scan, unsigned n_vox, const float4* vox, const float4* normals,
+              const int* vox_frame, int* fit_rank, uint32_t* fit_idx, float4* fit_pt, float4* fit_nrm,
+              int* fit_frame)
+{
+  const unsigned v = blockIdx.x * kBlock + threadIdx.x;
+  if (v >= n_vox) return;
+  if (flags[v]) {
+    const unsigned g = scan[v];
+    fit_rank[v] = (int)g;
+    fit_idx[g] = v;
+    fit_pt[g] = vox[v];
+    fit_nrm[g] = normals[v];
+    fit_frame[g] = vox_frame[v];
+  } else {
+    fit_rank[v] = -1;
+  }
+}
+
+__global__ void k_frame_fit_ranges(FrameInfo* fi, int n_frames, const uint32_t* scan)
+{
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n_frames) return;
+  const unsigned a = scan[fi[f].vox_start];
+  const unsigned b = scan[fi[f].vox_start + fi[f].n_vox];
+  fi[f].fit_start = (int)a;
+  fi[f].n_fit = (int)(b - a);
+}
+
+// ---- K8: exact k nearest neighbours among the fit points (z_growing.cpp:196-226) -------
+// Ring expansion over the column index until the k-th distance is provably smaller than
+// the distance to any column not yet visited.
+template <class KeyT, int KMAX>
+__global__ void __launch_bounds__(kBlock)
+k_knn(const float4* spt, const KeyT* skeys, const uint32_t* col_first, const int* vox_frame, const int* fit_rank,
+      const FrameInfo* fi, unsigned n_vox, float inv_xy, float inv_z, float cell_xy, int zbits, int K,
+      int* knn_out)
+{
+  const unsigned s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= n_vox) return;
+  const float4 q = spt[s];
+  const unsigned qv = __float_as_uint(q.w);
+  const int g = fit_rank[qv];
+  if (g < 0) return;
+  const FrameInfo& F = fi[vox_frame[qv]];
+  const int k = min(K, F.n_fit);
+  const int cqx = clampi(cell_unclamped(q.x, inv_xy, F.min_b[0]), 0, F.div_b[0] - 1);
+  const int cqy = clampi(cell_unclamped(q.y, inv_xy, F.min_b[1]), 0, F.div_b[1] - 1);
+
+  float bd[KMAX];
+  unsigned bi[KMAX];
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) {
+    bd[j] = INFINITY;
+    bi[j] = 0xffffffffu;
+  }
+  const int max_ring = max(max(cqx, F.div_b[0] - 1 - cqx), max(cqy, F.div_b[1] - 1 - cqy));
+  for (int R = 0; R <= max_ring; ++R) {
+    const int y0 = cqy - R, y1 = cqy + R, x0 = cqx - R, x1 = cqx + R;
+    for (int cy = max(y0, 0); cy <= min(y1, F.div_b[1] - 1); ++cy) {
+      const bool edge_row = (cy == y0 || cy == y1);
+      const int step = edge_row ? 1 : max(2 * R, 1);
+      for (int cx = x0; cx <= x1; cx += step) {
+        if (cx < 0 || cx >= F.div_b[0]) continue;
+        const unsigned col = (unsigned)F.col_off + (unsigned)(cy * F.div_b[0] + cx);
+        unsigned e = col_first[col];
+        const unsigned end = col_first[col + 1];
+        KeyT khi = ((KeyT)col << zbits) | (((KeyT)1 << zbits) - 1);
+        float worst = INFINITY;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j)
+          if (j == k - 1) worst = bd[j];
+        if (worst < INFINITY && end - e > 4) {
+          // list is full: only z within sqrt(worst) can still enter
+          const float rz = __builtin_sqrtf(worst) * 1.000001f + 1e-12f;
+          const int czlo = clampi(cell_unclamped(q.z - rz, inv_z, F.min_b[2]) - 1, 0, F.div_b[2] - 1);
+          const int czhi = clampi(cell_unclamped(q.z + rz, inv_z, F.min_b[2]) + 1, 0, F.div_b[2] - 1);
+          const KeyT klo = ((KeyT)col << zbits) | (KeyT)(unsigned)czlo;
+          khi = ((KeyT)col << zbits) | (KeyT)(unsigned)czhi;
+          unsigned hi = end;
+          while (e < hi) {
+            const unsigned mid = (e + hi) >> 1;
+            if (skeys[mid] < klo) e = mid + 1; else hi = mid;
+          }
+        }
+        for (; e < end && skeys[e] <= khi; ++e) {
+          const float4 p = spt[e];
+          const unsigned pv = __float_as_uint(p.w);
+          if (fit_rank[pv] < 0) continue;
+          const float d = dist2(q.x, q.y, q.z, p.x, p.y, p.z);
+          // sorted insertion with compile-time register indices
+          bool inserted_here;
+#pragma unroll
+          for (int j = KMAX - 1; j >= 1; --j) {
+            if (j < k) {
+              const bool before_prev = di_less(d, pv, bd[j - 1], bi[j - 1]);
+              inserted_here = di_less(d, pv, bd[j], bi[j]);
+              const float nd = before_prev ? bd[j - 1] : (inserted_here ? d : bd[j]);
+              const unsigned ni = before_prev ? bi[j - 1] : (inserted_here ? pv : bi[j]);
+              bd[j] = nd;
+              bi[j] = ni;
+            }
+          }
+          if (di_less(d, pv, bd[0], bi[0])) {
+            bd[0] = d;
+            bi[0] = pv;
+          }
+        }
+      }
+    }
+    // every unvisited column is more than (R - slack) cells away in x or y
+    const float reach = ((float)R - F.slack) * cell_xy * 0.999999f;
+    float kth = INFINITY;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j)
+      if (j == k - 1) kth = bd[j];
+    if (reach > 0.f && kth < reach * reach * 0.999999f) break;
+  }
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) {
+    if (j < K) knn_out[(size_t)g * K + j] = (j < k && bi[j] != 0xffffffffu) ? fit_rank[bi[j]] : -1;
+  }
+}
+
+// ---- K9: ZGrowing as min-rank reachability (z_growing.cpp:229-364) ----------------------
+// The reference grows regions breadth-first from seeds taken in the order std::sort
+// leaves n all-equal keys.  Because every finished region is closed under the (directed)
+// neighbour relation, the segment of a point is the smallest seed rank among all points
+// that can reach it; that fixed point is computed here by union-find over mutual edges
+// plus monotone atomicMin sweeps over the one-way edges.
+//
+// libstdc++ introsort on all-equal keys is data independent: each level swaps first<->mid
+// and reverses [first+1, last), then splits at first+1+(n-1)/2 while n > 16.  The element
+// that ends at position p is found by walking the split chain down and undoing the
+// levels bottom-up (tests/test_seed_order.py checks this against std::sort itself).
+__device__ inline int seed_at(int n, int p)
+{
+  int fs[40], ls[40];
+  int depth = 0;
+  int f = 0, l = n;
+  while (l - f > 16) {
+    fs[depth] = f;
+    ls[depth] = l;
+    ++depth;
+    const int cut = f + 1 + (l - f - 1) / 2;
+    if (p >= cut) f = cut; else l = cut;
+  }
+  for (int d = depth - 1; d >= 0; --d) {
+    f = fs[d];
+    l = ls[d];
+    const int mid = f + (l - f) / 2;
+    int s = (p == f) ? f : (l + f - p);
+    if (s == f) s = mid; else if (s == mid) s = f;
+    p = s;
+  }
+  return p;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_seed_ranks(const FrameInfo* fi, const int* fit_frame, unsigned n_fit, int* rank, int* seed_node, int* parent,
+             int* L)
+{
+  const unsigned g = blockIdx.x * kBlock + threadIdx.x;
+  if (g >= n_fit) return;
+  const FrameInfo& F = fi[fit_frame[g]];
+  const int p = (int)g - F.fit_start;
+  const int s = F.fit_start + seed_at(F.n_fit, p);
+  seed_node[g] = s;  // node seeded at global rank g
+  rank[s] = (int)g;  // global rank of node s
+  parent[g] = (int)g;
+  L[g] = 0x7fffffff;
+}
+
+__device__ __forceinline__ int uf_find(int* parent, int x)
+{
+  int p = parent[x];
+  while (p != x) {
+    const int gp = parent[p];
+    if (gp != p) parent[x] = gp;  // path halving (benign race: only ever points nearer the root)
+    x = p;
+    p = gp;
+  }
+  return x;
+}
+
+__device__ __forceinline__ bool z_edge(const float4* fit_pt, int a, int b, float th_z)
+{
+  return fabsf(fit_pt[a].z - fit_pt[b].z) < th_z;  // validatePoint, smooth mode
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_union_mutual(const int* knn, const float4* fit_pt, unsigned n_fit, int K, float th_z, int* parent)
+{
+  const unsigned g = blockIdx.x * kBlock + threadIdx.x;
+  if (g >= n_fit) return;
+  for (int j = 0; j < K; ++j) {
+    const int v = knn[(size_t)g * K + j];
+    if (v < 0) break;
+    if (v <= (int)g) continue;  // handle each mutual pair once (from the smaller index)
+    if (!z_edge(fit_pt, (int)g, v, th_z)) continue;
+    bool mutual = false;
+    for (int t = 0; t < K; ++t) mutual |= (knn[(size_t)v * K + t] == (int)g);
+    if (!mutual) continue;
+    int a = (int)g, b = v;
+    while (true) {
+      a = uf_find(parent, a);
+      b = uf_find(parent, b);
+      if (a == b) break;
+      if (a > b) {
+        const int t = a;
+        a = b;
+        b = t;
+      }
+      // hook the larger root under the smaller one
+      if (atomicCAS(&parent[b], b, a) == b) break;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_flatten_roots(int* parent, const int* rank, unsigned n_fit, int* root, int* L)
+{
+  const unsigned g = blockIdx.x * kBlock + threadIdx.x;
+  if (g >= n_fit) return;
+  int r = (int)g;
+  while (parent[r] != r) r = parent[r];
+  root[g] = r;
+  atomicMin(&L[r], rank[g]);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_label_sweep(const int* knn, const float4* fit_pt, const int* root, const int* seed_node, unsigned n_fit, int K,
+              float th_z, int* L, unsigned* changed)
+{
+  const unsigned g = blockIdx.x * kBlock + threadIdx.x;
+  if (g >= n_fit) return;
+  const int r = root[g];
+  int a = L[r];
+  bool ch = false;
+  if ((int)g == r) {
+    // shortcut: the seed that labels this component may itself carry a smaller label
+    const int w = seed_node[a];
+    const int aw = L[root[w]];
+    if (aw < a) {
+      atomicMin(&L[r], aw);
+      a = aw;
+      ch = true;
+    }
+  }
+  for (int j = 0; j < K; ++j) {
+    const int v = knn[(size_t)g * K + j];
+    if (v < 0) break;
+    if (v == (int)g) continue;
+    const int rv = root[v];
+    if (rv == r) continue;
+    if (!z_edge(fit_pt, (int)g, v, th_z)) continue;
+    if (a < L[rv]) {
+      const int old = atomicMin(&L[rv], a);
+      ch |= (a < old);
+    }
+  }
+  if (ch) *changed = 1u;
+}
+
+// per rank value: number of points whose segment was seeded at that rank
+__global__ void __launch_bounds__(kBlock)
+k_segment_sizes(const int* root, const int* L, unsigned n_fit, int* label, uint32_t* cnt)
+{
+  const unsigned g = blockIdx.x * kBlock + threadIdx.x;
+  if (g >= n_fit) return;
+  const int a = L[root[g]];
+  label[g] = a;
+  atomicAdd(&cnt[a], 1u);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_segment_flags(const uint32_t* cnt, unsigned n_fit, int min_cluster, uint32_t* is_seg, uint32_t* is_cl,
+                uint32_t* cl_pts)
+{
+  const unsigned r = blockIdx.x * kBlock + threadIdx.x;
+  if (r > n_fit) return;
+  const uint32_t c = r < n_fit ? cnt[r] : 0u;
+  is_seg[r] = c > 0u;
+  const bool cl = c >= (uint32_t)min_cluster;  // and <= INT_MAX, z_growing.cpp:153-154
+  is_cl[r] = cl;
+  cl_pts[r] = cl ? c : 0u;
+}
+
+__global__ void k_frame_cluster_ranges(FrameInfo* fi, int n_frames, const uint32_t* scan_seg,
+                                       const uint32_t* scan_cl)
+{
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n_frames) return;
+  const int a = fi[f].fit_start, b = fi[f].fit_start + fi[f].n_fit;
+  fi[f].seg_start = (int)scan_seg[a];
+  fi[f].n_segments = (int)(scan_seg[b] - scan_seg[a]);
+  fi[f].cl_start = (int)scan_cl[a];
+  fi[f].n_clusters = (int)(scan_cl[b] - scan_cl[a]);
+}
+
+// cluster id of every fit point (-1: its segment was dropped by the size filter) and the
+// sort key that groups members by cluster
+__global__ void __launch_bounds__(kBlock)
+k_point_clusters(const int* label, const uint32_t* is_cl, const uint32_t* scan_cl, unsigned n_fit,
+                 unsigned n_cl_total, int* cid, uint32_t* mkey, uint32_t* mval)
+{
+  const unsigned g = blockIdx.x * kBlock + threadIdx.x;
+  if (g >= n_fit) return;
+  const int a = label[g];
+  const int c = is_cl[a] ? (int)scan_cl[a] : -1;
+  cid[g] = c;
+  mkey[g] = c >= 0 ? (uint32_t)c : n_cl_total;
+  mval[g] = g;
+}
+
+struct ClusterRec {  // == hope_cluster
+  int size;
+  int pass;
+  float z_mean;
+  float min_x, min_y, max_x, max_y;
+  int seed_rank;
+};
+
+__global__ void __launch_bounds__(kBlock)
+k_cluster_heads(const uint32_t* cnt, const uint32_t* is_cl, const uint32_t* scan_cl, const uint32_t* scan_pts,
+                const int* seed_node, const int* fit_frame, const FrameInfo* fi, unsigned n_fit,
+                uint32_t* cl_first, ClusterRec* rec)
+{
+  const unsigned r = blockIdx.x * kBlock + threadIdx.x;
+  if (r >= n_fit || !is_cl[r]) return;
+  const unsigned c = scan_cl[r];
+  cl_first[c] = scan_pts[r];
+  rec[c].size = (int)cnt[r];
+  rec[c].seed_rank = (int)r - fi[fit_frame[seed_node[r]]].fit_start;
+}
+
+// Utilities::normalAnalysis's 2x2 principal axis (closed form; see oracle header note)
+__device__ inline void principal_axis_2x2(float a, float b, float d, float& ax, float& ay)
+{
+  const float p = 0.5f * (a - d);
+  const float z = __builtin_sqrtf(p * p + b * b);
+  if (z == 0.f) {
+    ax = 0.f;
+    ay = 1.f;
+    return;
+  }
+  float vx, vy;
+  if (p >= 0.f) {
+    vx = p + z;
+    vy = b;
+  } else {
+    vx = b;
+    vy = z - p;
+  }
+  const float nrm = __builtin_sqrtf(vx * vx + vy * vy);
+  ax = vx / nrm;
+  ay = vy / nrm;
+}
+
+// ---- K10: A10 mean z (utilities.cpp:751-769), A12 bbox (plane_segment.cpp:408-420),
+// A11 normalAnalysis (utilities.cpp:151-282).  One thread per cluster: every sum is the
+// reference's sequential float sum over the members in ascending index.
+__global__ void __launch_bounds__(kWave)
+k_cluster_verify(const uint32_t* members, const uint32_t* cl_first, const float4* fit_pt, const float4* fit_nrm,
+                 unsigned n_cl, float th_angle, ClusterRec* rec)
+{
+  const unsigned c = blockIdx.x * kWave + threadIdx.x;
+  if (c >= n_cl) return;
+  const uint32_t* m = members + cl_first[c];
+  const int sz = rec[c].size;
+  float mid = 0.f;
+  unsigned ct = 0;
+  float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int i = 0; i < sz; ++i) {
+    const unsigned g = m[i];
+    const float4 p = fit_pt[g];
+    const float4 nn = fit_nrm[g];
+    if (isfinite(p.z)) {
+      mid += p.z;
+      ++ct;
+    }
+    mnx = fminf(mnx, p.x);
+    mny = fminf(mny, p.y);
+    mxx = fmaxf(mxx, p.x);
+    mxy = fmaxf(mxy, p.y);
+    s0 += nn.x;
+    s1 += nn.y;
+    s2 += fabsf(nn.z);
+  }
+  rec[c].z_mean = mid / (float)ct;
+  rec[c].min_x = mnx;
+  rec[c].min_y = mny;
+  rec[c].max_x = mxx;
+  rec[c].max_y = mxy;
+  int pass = 0;
+  if (sz > 2) {
+    const float fsz = (float)sz;
+    const float m0 = s0 / fsz, m1 = s1 / fsz, m2 = s2 / fsz;
+    const float proj_norm = __builtin_sqrtf(m0 * m0 + m1 * m1);
+    const float mean_norm = __builtin_sqrtf(m0 * m0 + (m1 * m1 + m2 * m2));
+    const float grad = hope_det_asinf(proj_norm / mean_norm);
+    if (!(grad > th_angle)) {
+      float cxx = 0.f, cxy = 0.f, cyy = 0.f;
+      for (int i = 0; i < sz; ++i) {
+        const float4 nn = fit_nrm[m[i]];
+        const float tx = nn.x - m0, ty = nn.y - m1;
+        cxx += tx * tx;
+        cxy += tx * ty;
+        cyy += ty * ty;
+      }
+      const float denom = (float)(sz - 1);
+      cxx /= denom;
+      cxy /= denom;
+      cyy /= denom;
+      float ax, ay;
+      principal_axis_2x2(cxx, cxy, cyy, ax, ay);
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+      unsigned na = 0, nb = 0;
+      for (int i = 0; i < sz; ++i) {
+        const float4 nn = fit_nrm[m[i]];
+        const float nz = fabsf(nn.z);
+        const float tx = nn.x - m0, ty = nn.y - m1;
+        if (ax * tx + ay * ty > 0.f) {
+          a0 += nn.x;
+          a1 += nn.y;
+          a2 += nz;
+          ++na;
+        } else {
+          b0 += nn.x;
+          b1 += nn.y;
+          b2 += nz;
+          ++nb;
+        }
+      }
+      if (na != 0 && nb != 0) {
+        const float fa = (float)na, fb = (float)nb;
+        const float p1[3] = {a0 / fa, a1 / fa, a2 / fa};
+        const float p2[3] = {b0 / fb, b1 / fb, b2 / fb};
+        const float mu = p2[0] * p1[0] + (p2[1] * p1[1] + p2[2] * p1[2]);
+        const float n1 = __builtin_sqrtf(sqnorm3(p1));
+        const float n2 = __builtin_sqrtf(sqnorm3(p2));
+        const float rad_mu = hope_det_acosf(mu / (n1 * n2));
+        pass = (rad_mu <= th_angle) ? 1 : 0;
+      }
+    }
+  }
+  rec[c].pass = pass;
+}
+
+// ---- on-demand export of the transformed cloud (hope_get_transformed) -------------------
+template <class Src>
+__global__ void __launch_bounds__(kBlock)
+k_valid_flags(Src src, const FrameInfo* fi, int frame, uint32_t* flags)
+{
+  const unsigned n = src_count(src);
+  const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+  if (i > n) return;
+  float x, y, z;
+  flags[i] = (i < n && load_point(src, fi, frame, i, x, y, z)) ? 1u : 0u;
+}
+
+template <class Src>
+__global__ void __launch_bounds__(kBlock)
+k_export_transformed(Src src, const FrameInfo* fi, int frame, const uint32_t* scan, float* xyz, int* src_index)
+{
+  const unsigned n = src_count(src);
+  const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  float x, y, z;
+  if (load_point(src, fi, frame, i, x, y, z)) {
+    const unsigned o = scan[i];
+    xyz[3 * (size_t)o] = x;
+    xyz[3 * (size_t)o + 1] = y;
+    xyz[3 * (size_t)o + 2] = z;
+    src_index[o] = (int)i;
+  }
+}
+
+}  // namespace hope
