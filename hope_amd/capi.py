@@ -120,6 +120,19 @@ class HopeLib:
             f.restype = res
             f.argtypes = args
             self.fn[name] = f
+        # instrumentation entry points exist in the HIP library only
+        self.has_profile = hasattr(self.dll, prefix + "profile_enable")
+        if self.has_profile:
+            f = getattr(self.dll, prefix + "profile_enable")
+            f.restype, f.argtypes = C.c_int, [vp, i32]
+            self.fn["profile_enable"] = f
+            f = getattr(self.dll, prefix + "profile_stage_count")
+            f.restype, f.argtypes = C.c_int, []
+            self.fn["profile_stage_count"] = f
+            f = getattr(self.dll, prefix + "profile_stage")
+            f.restype = C.c_int
+            f.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+            self.fn["profile_stage"] = f
 
     def default_config(self):
         cfg = HopeConfig()
@@ -278,6 +291,18 @@ class HopeContext:
         m = HopeMaxPlane()
         self._check(self.lib.fn["get_max_plane"](self._h, frame, C.byref(m)), "get_max_plane")
         return m
+
+    def profile_enable(self, on=True):
+        self._check(self.lib.fn["profile_enable"](self._h, 1 if on else 0), "profile_enable")
+
+    def profile(self):
+        """[(stage name, total device ms, launches)] accumulated since profile_enable()."""
+        out = []
+        for i in range(self.lib.fn["profile_stage_count"]()):
+            name, ms, n = C.c_char_p(), C.c_double(), C.c_int64()
+            self.lib.fn["profile_stage"](self._h, i, C.byref(name), C.byref(ms), C.byref(n))
+            out.append((name.value.decode(), ms.value, n.value))
+        return out
 
     def timing(self):
         a, b = C.c_double(), C.c_double()

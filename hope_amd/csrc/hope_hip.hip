@@ -83,6 +83,30 @@ inline int bits_for(unsigned long long v)  // bits needed to represent values 0.
 
 inline unsigned nblk(size_t n, int per = kBlock) { return (unsigned)((n + per - 1) / per); }
 
+// Optional per-stage timing with HIP events recorded on the ctx stream (bench.py's roofline
+// figures come from here; off by default).
+enum Stage {
+  ST_BBOX, ST_GRID, ST_VKEYS, ST_VSORT, ST_VRLE, ST_CENTROID, ST_COLKEYS, ST_COLSORT, ST_COLTABLE, ST_NORMALS,
+  ST_FIT, ST_KNN, ST_LABELS, ST_SEGMENTS, ST_VERIFY, ST_COUNT
+};
+const char* const kStageNames[ST_COUNT] = {
+  "k_bbox", "k_frame_grid", "k_voxel_keys", "voxel_sort(rocprim)", "voxel_rle+scan(rocprim)", "k_centroids",
+  "k_column_keys", "column_sort(rocprim)", "k_column_table+gather", "k_normals", "fit_gate+compact", "k_knn",
+  "labels(union+sweeps)", "segments(scan+sort)", "k_cluster_verify"};
+
+struct Prof {
+  int on = 0;
+  std::vector<hipEvent_t> ev;
+  size_t used = 0;
+  struct Rec {
+    int st;
+    size_t a, b;
+  };
+  std::vector<Rec> recs;
+  double ms[ST_COUNT] = {};
+  long long launches[ST_COUNT] = {};
+};
+
 }  // namespace
 
 struct hope_ctx {
@@ -101,6 +125,7 @@ struct hope_ctx {
   std::string err;
   double whole_ms = 0, ref_ms = 0;
   int normals_cap_small = 0;  // test knob: force the neighbour-list overflow path
+  Prof prof;
 
   // ---- state of the last call --------------------------------------------------------
   int n_frames = 0;
@@ -189,6 +214,43 @@ int sync_globals(hope_ctx* c)
   return HOPE_OK;
 }
 
+size_t prof_mark(hope_ctx* c)
+{
+  Prof& p = c->prof;
+  if (!p.on) return 0;
+  if (p.used == p.ev.size()) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) {
+      p.on = 0;
+      return 0;
+    }
+    p.ev.push_back(e);
+  }
+  (void)hipEventRecord(p.ev[p.used], c->stream);
+  return p.used++;
+}
+
+void prof_close(hope_ctx* c, int st, size_t a)
+{
+  if (!c->prof.on) return;
+  const size_t b = prof_mark(c);
+  c->prof.recs.push_back(Prof::Rec{st, a, b});
+}
+
+void prof_collect(hope_ctx* c)  // call after the stream has been synchronised
+{
+  Prof& p = c->prof;
+  for (const Prof::Rec& r : p.recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.ev[r.a], p.ev[r.b]) == hipSuccess) {
+      p.ms[r.st] += ms;
+      p.launches[r.st] += 1;
+    }
+  }
+  p.recs.clear();
+  p.used = 0;
+}
+
 // PlaneSegmentRT::getPlane's winner logic over the cluster records (plane_segment.cpp:930-962)
 void rt_post(hope_ctx* c)
 {
@@ -246,13 +308,18 @@ int stage_voxel(hope_ctx* c, const Src& src, size_t n_per_frame, int cell_bits, 
   ALLOC(v_in, uint32_t, N);
   ALLOC(v_out, uint32_t, N);
   const unsigned bx = std::min<unsigned>(nblk(n_per_frame), 4096u);
+  size_t pm = prof_mark(c);
   hipLaunchKernelGGL((k_voxel_keys<Src, VK>), dim3(bx, F), dim3(kBlock), 0, s, src, c->d_fi, c->inv_xy, c->inv_z,
                      cell_bits, F, k_in, v_in);
+  prof_close(c, ST_VKEYS, pm);
+  pm = prof_mark(c);
   if (sizeof(VK) == 4) {
     HIPCHK(sort_pairs_u32(pa, (const uint32_t*)k_in, (uint32_t*)k_out, v_in, v_out, N, total_bits, s));
   } else {
     HIPCHK(sort_pairs_u64(pa, (const uint64_t*)k_in, (uint64_t*)k_out, v_in, v_out, N, total_bits, s));
   }
+  prof_close(c, ST_VSORT, pm);
+  pm = prof_mark(c);
   // k_in / v_in are dead now: reuse them for the run-length outputs
   uniq = k_in;
   run_cnt = v_in;
@@ -265,16 +332,21 @@ int stage_voxel(hope_ctx* c, const Src& src, size_t n_per_frame, int cell_bits, 
   hipLaunchKernelGGL((k_frame_vox_ranges<VK>), dim3(nblk(F + 1)), dim3(kBlock), 0, s, c->d_fi, F, uniq,
                      &c->d_glob->n_runs, cell_bits, c->d_glob);
   hipLaunchKernelGGL(k_frame_vox_counts, dim3(nblk(F)), dim3(kBlock), 0, s, c->d_fi, F, c->d_glob);
+  prof_close(c, ST_VRLE, pm);
   int st = sync_globals(c);
   if (st != HOPE_OK) return st;
   const unsigned n_vox = c->h_glob->n_vox_total;
   c->n_vox_total = n_vox;
   if (n_vox == 0) return HOPE_OK;
+  pm = prof_mark(c);
   HIPCHK(exclusive_scan_u32(pa, run_cnt, run_start, n_vox, s));
+  prof_close(c, ST_VRLE, pm);
   ALLOC(d_vox, float4, n_vox);
   ALLOC(d_vox_frame, int, n_vox);
+  pm = prof_mark(c);
   hipLaunchKernelGGL((k_centroids<Src, VK>), dim3(nblk(n_vox)), dim3(kBlock), 0, s, src, c->d_fi, uniq, run_start,
                      run_cnt, v_out, n_vox, cell_bits, d_vox, d_vox_frame);
+  prof_close(c, ST_CENTROID, pm);
   return HOPE_OK;
 }
 
@@ -298,21 +370,28 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   ALLOC(cv_out, uint32_t, n_vox);
   ALLOC(col_first, uint32_t, (size_t)total_cols + 1);
   ALLOC(spt, float4, n_vox);
+  size_t pm = prof_mark(c);
   hipLaunchKernelGGL((k_column_keys<CK>), dim3(nblk(n_vox)), dim3(kBlock), 0, s, d_vox, d_vox_frame, c->d_fi,
                      n_vox, c->inv_xy, c->inv_z, zbits, ck_in, cv_in);
+  prof_close(c, ST_COLKEYS, pm);
+  pm = prof_mark(c);
   if (sizeof(CK) == 4) {
     HIPCHK(sort_pairs_u32(pa, (const uint32_t*)ck_in, (uint32_t*)ck_out, cv_in, cv_out, n_vox, key2_bits, s));
   } else {
     HIPCHK(sort_pairs_u64(pa, (const uint64_t*)ck_in, (uint64_t*)ck_out, cv_in, cv_out, n_vox, key2_bits, s));
   }
+  prof_close(c, ST_COLSORT, pm);
+  pm = prof_mark(c);
   hipLaunchKernelGGL((k_column_table<CK>), dim3(nblk((size_t)total_cols + 1)), dim3(kBlock), 0, s, ck_out, n_vox,
                      total_cols, zbits, col_first);
   hipLaunchKernelGGL(k_gather_sorted, dim3(nblk(n_vox)), dim3(kBlock), 0, s, d_vox, cv_out, n_vox, spt);
+  prof_close(c, ST_COLTABLE, pm);
 
   // ---- A6 normals -----------------------------------------------------------------
   float4* d_normals;
   ALLOC(d_normals, float4, n_vox);
   c->d_normals = d_normals;
+  pm = prof_mark(c);
   if (c->normals_cap_small) {
     hipLaunchKernelGGL((k_normals<CK, 4>), dim3(nblk(n_vox)), dim3(kBlock), 0, s, spt, ck_out, col_first,
                        d_vox_frame, c->d_fi, n_vox, c->inv_xy, c->inv_z, zbits, c->radius, c->r2, c->ring,
@@ -323,14 +402,17 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
                        d_normals);
   }
 
+  prof_close(c, ST_NORMALS, pm);
   // ---- A7 gate + compaction ---------------------------------------------------------
   uint32_t *flags, *fscan;
   ALLOC(flags, uint32_t, (size_t)n_vox + 1);
   ALLOC(fscan, uint32_t, (size_t)n_vox + 1);
+  pm = prof_mark(c);
   hipLaunchKernelGGL(k_fit_flags, dim3(nblk((size_t)n_vox + 1)), dim3(kBlock), 0, s, d_normals, n_vox, c->th_norm,
                      flags);
   HIPCHK(exclusive_scan_u32(pa, flags, fscan, (size_t)n_vox + 1, s));
   hipLaunchKernelGGL(k_frame_fit_ranges, dim3(nblk(F)), dim3(kBlock), 0, s, c->d_fi, F, fscan);
+  prof_close(c, ST_FIT, pm);
   uint32_t* h_cnt = reinterpret_cast<uint32_t*>(&c->h_glob->pad);
   HIPCHK(hipMemcpyAsync(h_cnt, fscan + n_vox, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
@@ -346,8 +428,10 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   ALLOC(fit_nrm, float4, std::max(n_fit, 1u));
   ALLOC(fit_frame, int, std::max(n_fit, 1u));
   c->d_fit_idx = fit_idx;
+  pm = prof_mark(c);
   hipLaunchKernelGGL(k_fit_scatter, dim3(nblk(n_vox)), dim3(kBlock), 0, s, flags, fscan, n_vox, d_vox, d_normals,
                      d_vox_frame, fit_rank, fit_idx, fit_pt, fit_nrm, fit_frame);
+  prof_close(c, ST_FIT, pm);
   if (n_fit == 0) return HOPE_OK;
 
   HIPCHK(hipEventRecord(c->ev_a, s));  // the reference's timer window opens (plane_segment.cpp:157)
@@ -356,6 +440,7 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   int* knn;
   ALLOC(knn, int, (size_t)n_fit * K);
   c->d_knn = knn;
+  pm = prof_mark(c);
   if (K <= 8) {
     hipLaunchKernelGGL((k_knn<CK, 8>), dim3(nblk(n_vox)), dim3(kBlock), 0, s, spt, ck_out, col_first, d_vox_frame,
                        fit_rank, c->d_fi, n_vox, c->inv_xy, c->inv_z, c->cfg.th_xy, zbits, K, knn);
@@ -364,6 +449,7 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
                        d_vox_frame, fit_rank, c->d_fi, n_vox, c->inv_xy, c->inv_z, c->cfg.th_xy, zbits, K, knn);
   }
 
+  prof_close(c, ST_KNN, pm);
   // ---- A9 region growing as min-rank reachability -----------------------------------
   int *rank, *seed_node, *parent, *L, *root, *label;
   ALLOC(rank, int, n_fit);
@@ -373,15 +459,19 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   ALLOC(root, int, n_fit);
   ALLOC(label, int, n_fit);
   const unsigned gb = nblk(n_fit);
+  pm = prof_mark(c);
   hipLaunchKernelGGL(k_seed_ranks, dim3(gb), dim3(kBlock), 0, s, c->d_fi, fit_frame, n_fit, rank, seed_node, parent,
                      L);
   hipLaunchKernelGGL(k_union_mutual, dim3(gb), dim3(kBlock), 0, s, knn, fit_pt, n_fit, K, c->cfg.th_z, parent);
   hipLaunchKernelGGL(k_flatten_roots, dim3(gb), dim3(kBlock), 0, s, parent, rank, n_fit, root, L);
+  prof_close(c, ST_LABELS, pm);
   for (int iter = 0; iter < 100000; ++iter) {
+    pm = prof_mark(c);
     HIPCHK(hipMemsetAsync(&c->d_glob->changed, 0, sizeof(unsigned), s));
     for (int rep = 0; rep < 2; ++rep)
       hipLaunchKernelGGL(k_label_sweep, dim3(gb), dim3(kBlock), 0, s, knn, fit_pt, root, seed_node, n_fit, K,
                          c->cfg.th_z, L, &c->d_glob->changed);
+    prof_close(c, ST_LABELS, pm);
     int st = sync_globals(c);
     if (st != HOPE_OK) return st;
     if (!c->h_glob->changed) break;
@@ -396,6 +486,7 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   ALLOC(scan_seg, uint32_t, (size_t)n_fit + 1);
   ALLOC(scan_cl, uint32_t, (size_t)n_fit + 1);
   ALLOC(scan_pts, uint32_t, (size_t)n_fit + 1);
+  pm = prof_mark(c);
   HIPCHK(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * ((size_t)n_fit + 1), s));
   hipLaunchKernelGGL(k_segment_sizes, dim3(gb), dim3(kBlock), 0, s, root, L, n_fit, label, cnt);
   hipLaunchKernelGGL(k_segment_flags, dim3(nblk((size_t)n_fit + 1)), dim3(kBlock), 0, s, cnt, n_fit,
@@ -404,6 +495,7 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   HIPCHK(exclusive_scan_u32(pa, is_cl, scan_cl, (size_t)n_fit + 1, s));
   HIPCHK(exclusive_scan_u32(pa, cl_pts, scan_pts, (size_t)n_fit + 1, s));
   hipLaunchKernelGGL(k_frame_cluster_ranges, dim3(nblk(F)), dim3(kBlock), 0, s, c->d_fi, F, scan_seg, scan_cl);
+  prof_close(c, ST_SEGMENTS, pm);
   HIPCHK(hipMemcpyAsync(h_cnt, scan_cl + n_fit, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   const unsigned n_cl = *h_cnt;
@@ -422,17 +514,24 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   c->d_cid = cid;
   c->d_members = members;
   c->d_cl_first = cl_first;
+  pm = prof_mark(c);
   hipLaunchKernelGGL(k_point_clusters, dim3(gb), dim3(kBlock), 0, s, label, is_cl, scan_cl, n_fit, n_cl, cid, mkey,
                      mval);
   if (n_cl > 0) {
     HIPCHK(sort_pairs_u32(pa, mkey, mkey_s, mval, members, n_fit, bits_for(n_cl), s));
     hipLaunchKernelGGL(k_cluster_heads, dim3(gb), dim3(kBlock), 0, s, cnt, is_cl, scan_cl, scan_pts, seed_node,
                        fit_frame, c->d_fi, n_fit, cl_first, rec);
+    prof_close(c, ST_SEGMENTS, pm);
+    pm = prof_mark(c);
     // ---- A10..A12 -------------------------------------------------------------------
     hipLaunchKernelGGL(k_cluster_verify, dim3(nblk(n_cl, kWave)), dim3(kWave), 0, s, members, cl_first, fit_pt,
                        fit_nrm, n_cl, c->th_angle, rec);
+    prof_close(c, ST_VERIFY, pm);
     c->h_rec.resize(n_cl);
     HIPCHK(hipMemcpyAsync(c->h_rec.data(), rec, sizeof(ClusterRec) * n_cl, hipMemcpyDeviceToHost, s));
+  }
+  else {
+    prof_close(c, ST_SEGMENTS, pm);
   }
   HIPCHK(hipEventRecord(c->ev_b, s));  // the window closes (plane_segment.cpp:168)
   return HOPE_OK;
@@ -445,6 +544,8 @@ int run_pipeline(hope_ctx* c, const Src& src, size_t n_per_frame)
   hipStream_t s = c->stream;
   const auto t0 = std::chrono::steady_clock::now();
   c->ref_ms = 0;
+  c->prof.recs.clear();
+  c->prof.used = 0;
   c->n_vox_total = c->n_fit_total = c->n_cl_total = 0;
   c->h_rec.clear();
   c->h_nplanes.assign(F, 0);
@@ -480,9 +581,15 @@ int run_pipeline(hope_ctx* c, const Src& src, size_t n_per_frame)
   // ---- A1..A3 + bbox ------------------------------------------------------------------
   if (n_per_frame > 0) {
     const unsigned bx = std::max(1u, std::min<unsigned>(nblk(n_per_frame, kBlock * 8), 2048u));
+    size_t pm = prof_mark(c);
     hipLaunchKernelGGL((k_bbox<Src>), dim3(bx, F), dim3(kBlock), 0, s, src, d_fi);
+    prof_close(c, ST_BBOX, pm);
   }
-  hipLaunchKernelGGL(k_frame_grid, dim3(1), dim3(64), 0, s, d_fi, F, c->inv_xy, c->inv_z, c->d_glob);
+  {
+    size_t pm = prof_mark(c);
+    hipLaunchKernelGGL(k_frame_grid, dim3(1), dim3(64), 0, s, d_fi, F, c->inv_xy, c->inv_z, c->d_glob);
+    prof_close(c, ST_GRID, pm);
+  }
   int st = sync_globals(c);
   if (st != HOPE_OK) return st;
   if (c->h_glob->any_overflow) {
@@ -519,6 +626,7 @@ int run_pipeline(hope_ctx* c, const Src& src, size_t n_per_frame)
   }
   HIPCHK(hipMemcpyAsync(c->h_fi.data(), d_fi, sizeof(FrameInfo) * F, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
+  prof_collect(c);
   if (timed) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, c->ev_a, c->ev_b) == hipSuccess) c->ref_ms = ms;
@@ -600,6 +708,7 @@ HOPE_API void hope_destroy(hope_ctx* c)
   c->arena.release();
   if (c->d_glob) (void)hipFree(c->d_glob);
   if (c->h_glob) (void)hipHostFree(c->h_glob);
+  for (hipEvent_t e : c->prof.ev) (void)hipEventDestroy(e);
   if (c->ev_a) (void)hipEventDestroy(c->ev_a);
   if (c->ev_b) (void)hipEventDestroy(c->ev_b);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -869,6 +978,28 @@ HOPE_API int hope_get_max_plane(hope_ctx* c, int frame, hope_max_plane* out)
   GET_FRAME(c, frame);
   if (!out) return HOPE_E_INVALID;
   *out = c->h_max[frame];
+  return HOPE_OK;
+}
+
+HOPE_API int hope_profile_enable(hope_ctx* c, int on)
+{
+  if (!c) return HOPE_E_INVALID;
+  c->prof.on = on ? 1 : 0;
+  for (int i = 0; i < ST_COUNT; ++i) {
+    c->prof.ms[i] = 0;
+    c->prof.launches[i] = 0;
+  }
+  return HOPE_OK;
+}
+
+HOPE_API int hope_profile_stage_count(void) { return ST_COUNT; }
+
+HOPE_API int hope_profile_stage(hope_ctx* c, int stage, const char** name, double* total_ms, int64_t* launches)
+{
+  if (!c || stage < 0 || stage >= ST_COUNT) return HOPE_E_RANGE;
+  if (name) *name = kStageNames[stage];
+  if (total_ms) *total_ms = c->prof.ms[stage];
+  if (launches) *launches = c->prof.launches[stage];
   return HOPE_OK;
 }
 

@@ -170,6 +170,14 @@ HOPE_API int hope_get_max_plane(hope_ctx* ctx, int frame, hope_max_plane* out);
  * window (findAllPlanes only, plane_segment.cpp:157-169) */
 HOPE_API int hope_last_timing(hope_ctx* ctx, double* whole_ms, double* ref_window_ms);
 
+/* ---- instrumentation (HIP library only; no counterpart in the reference) ------------- */
+/* Per-stage device time measured with HIP events on the ctx stream, accumulated over the
+ * segment calls made while enabled.  hope_profile_enable also clears the accumulators. */
+HOPE_API int hope_profile_enable(hope_ctx* ctx, int on);
+HOPE_API int hope_profile_stage_count(void);
+HOPE_API int hope_profile_stage(hope_ctx* ctx, int stage, const char** name, double* total_ms,
+                                int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif
