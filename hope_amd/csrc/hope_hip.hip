@@ -344,8 +344,8 @@ int stage_voxel(hope_ctx* c, const Src& src, size_t n_per_frame, int cell_bits, 
   ALLOC(d_vox, float4, n_vox);
   ALLOC(d_vox_frame, int, n_vox);
   pm = prof_mark(c);
-  hipLaunchKernelGGL((k_centroids<Src, VK>), dim3(nblk(n_vox)), dim3(kBlock), 0, s, src, c->d_fi, uniq, run_start,
-                     run_cnt, v_out, n_vox, cell_bits, d_vox, d_vox_frame);
+  hipLaunchKernelGGL((k_centroids_w<Src, VK>), dim3(nblk(n_vox, kWave)), dim3(kWave), 0, s, src, c->d_fi, uniq,
+                     run_start, run_cnt, v_out, n_vox, cell_bits, d_vox, d_vox_frame);
   prof_close(c, ST_CENTROID, pm);
   return HOPE_OK;
 }
@@ -524,8 +524,8 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
     prof_close(c, ST_SEGMENTS, pm);
     pm = prof_mark(c);
     // ---- A10..A12 -------------------------------------------------------------------
-    hipLaunchKernelGGL(k_cluster_verify, dim3(nblk(n_cl, kWave)), dim3(kWave), 0, s, members, cl_first, fit_pt,
-                       fit_nrm, n_cl, c->th_angle, rec);
+    hipLaunchKernelGGL(k_cluster_verify_w, dim3(n_cl), dim3(kWave), 0, s, members, cl_first, fit_pt, fit_nrm, n_cl,
+                       c->th_angle, rec);
     prof_close(c, ST_VERIFY, pm);
     c->h_rec.resize(n_cl);
     HIPCHK(hipMemcpyAsync(c->h_rec.data(), rec, sizeof(ClusterRec) * n_cl, hipMemcpyDeviceToHost, s));

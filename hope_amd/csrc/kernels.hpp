@@ -318,6 +318,67 @@ k_centroids(Src src, const FrameInfo* fi, const KeyT* unique, const uint32_t* ru
   vox_frame[v] = frame;
 }
 
+// ---- K5 (wave-cooperative): same sums, fed through LDS -----------------------------------
+// A wave owns 64 consecutive voxels (lane = voxel).  Per round it fetches the next kR entries
+// of every voxel with coalesced loads (16 lanes per voxel), re-derives the points in parallel,
+// parks them in LDS and then every lane adds ITS voxel's kR points sequentially — the same
+// ascending-index chain as the one-thread-per-voxel kernel above, but with 64 chains per wave
+// running from LDS instead of 64 dependent uncoalesced gathers.
+constexpr int kR = 16;          // entries per voxel per round
+constexpr int kRStride = 65;    // LDS row stride (dwords): conflict-free reads, <=4-way writes
+
+template <class Src, class KeyT>
+__global__ void __launch_bounds__(kWave)
+k_centroids_w(Src src, const FrameInfo* fi, const KeyT* unique, const uint32_t* run_start, const uint32_t* run_count,
+              const uint32_t* vals_sorted, unsigned n_vox, int cell_bits, float4* vox, int* vox_frame)
+{
+  __shared__ float s_x[kR * kRStride], s_y[kR * kRStride], s_z[kR * kRStride];
+  const int lane = threadIdx.x;
+  const unsigned v = blockIdx.x * kWave + lane;
+  const bool live = v < n_vox;
+  const int frame = live ? (int)(unique[v] >> cell_bits) : 0;
+  const unsigned my_start = live ? run_start[v] : 0u;
+  const unsigned my_cnt = live ? run_count[v] : 0u;
+  const unsigned n = src_count(src);
+  unsigned max_cnt = my_cnt;
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) max_cnt = max(max_cnt, (unsigned)__shfl_xor((int)max_cnt, off));
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  const int sub = lane & (kR - 1);   // entry within the round
+  const int grp = lane / kR;         // which of the 4 voxels this load serves
+  for (unsigned r0 = 0; r0 < max_cnt; r0 += kR) {
+#pragma unroll 4
+    for (int q = 0; q < kWave / (kWave / kR); ++q) {
+      const int vl = q * (kWave / kR) + grp;
+      const unsigned cnt_v = (unsigned)__shfl((int)my_cnt, vl);
+      const unsigned start_v = (unsigned)__shfl((int)my_start, vl);
+      const int frame_v = __shfl(frame, vl);
+      const unsigned e = r0 + sub;
+      if (e < cnt_v) {
+        const unsigned i = (unsigned)(vals_sorted[start_v + e] - (unsigned)((size_t)frame_v * n));
+        float x, y, z;
+        load_point(src, fi, frame_v, i, x, y, z);
+        s_x[sub * kRStride + vl] = x;
+        s_y[sub * kRStride + vl] = y;
+        s_z[sub * kRStride + vl] = z;
+      }
+    }
+    __syncthreads();
+    const int k = (int)min((unsigned)kR, my_cnt > r0 ? my_cnt - r0 : 0u);
+    for (int j = 0; j < k; ++j) {
+      sx += s_x[j * kRStride + lane];
+      sy += s_y[j * kRStride + lane];
+      sz += s_z[j * kRStride + lane];
+    }
+    __syncthreads();
+  }
+  if (live) {
+    const float c = (float)my_cnt;
+    vox[v] = make_float4(sx / c, sy / c, sz / c, 0.f);
+    vox_frame[v] = frame;
+  }
+}
+
 // ---- column index over the down-sampled cloud -----------------------------------------
 // Index function (any monotone function is exact, it only steers the search):
 // col = clamp(floor(x*inv) - min_b), cz likewise; key2 = (col_off + cy*div_x + cx) << zbits | cz
@@ -858,15 +919,49 @@ k_union_mutual(const int* knn, const float4* fit_pt, unsigned n_fit, int K, floa
   }
 }
 
+// One atomic per distinct key per wave: neighbouring points mostly share a root / label, so
+// thousands of same-address atomics collapse to a handful.
+__device__ __forceinline__ void wave_atomic_min_by_key(int* table, int key, int val, bool active)
+{
+  unsigned long long todo = __ballot(active);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int k = __shfl(key, leader);
+    const bool mine = active && key == k;
+    const unsigned long long grp = __ballot(mine);
+    int m = mine ? val : 0x7fffffff;
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) m = min(m, __shfl_xor(m, off));
+    if ((threadIdx.x & (kWave - 1)) == leader) atomicMin(&table[k], m);
+    todo &= ~grp;
+  }
+}
+
+__device__ __forceinline__ void wave_atomic_count_by_key(uint32_t* table, int key, bool active)
+{
+  unsigned long long todo = __ballot(active);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int k = __shfl(key, leader);
+    const unsigned long long grp = __ballot(active && key == k);
+    if ((threadIdx.x & (kWave - 1)) == leader) atomicAdd(&table[k], (uint32_t)__popcll(grp));
+    todo &= ~grp;
+  }
+}
+
 __global__ void __launch_bounds__(kBlock)
 k_flatten_roots(int* parent, const int* rank, unsigned n_fit, int* root, int* L)
 {
   const unsigned g = blockIdx.x * kBlock + threadIdx.x;
-  if (g >= n_fit) return;
-  int r = (int)g;
-  while (parent[r] != r) r = parent[r];
-  root[g] = r;
-  atomicMin(&L[r], rank[g]);
+  const bool active = g < n_fit;
+  int r = 0, rk = 0x7fffffff;
+  if (active) {
+    r = (int)g;
+    while (parent[r] != r) r = parent[r];
+    root[g] = r;
+    rk = rank[g];
+  }
+  wave_atomic_min_by_key(L, r, rk, active);
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -908,10 +1003,13 @@ __global__ void __launch_bounds__(kBlock)
 k_segment_sizes(const int* root, const int* L, unsigned n_fit, int* label, uint32_t* cnt)
 {
   const unsigned g = blockIdx.x * kBlock + threadIdx.x;
-  if (g >= n_fit) return;
-  const int a = L[root[g]];
-  label[g] = a;
-  atomicAdd(&cnt[a], 1u);
+  const bool active = g < n_fit;
+  int a = 0;
+  if (active) {
+    a = L[root[g]];
+    label[g] = a;
+  }
+  wave_atomic_count_by_key(cnt, a, active);
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -1087,6 +1185,155 @@ k_cluster_verify(const uint32_t* members, const uint32_t* cl_first, const float4
     }
   }
   rec[c].pass = pass;
+}
+
+// ---- K10 (wave per cluster) --------------------------------------------------------------
+// Same sequential sums as k_cluster_verify, organised for the hardware: the 64 lanes fetch the
+// members' points / normals with coalesced index loads, form the per-point terms in parallel and
+// park them in LDS; then one lane per accumulator runs its chain over the tile in member order.
+constexpr int kVTile = 256;
+
+__global__ void __launch_bounds__(kWave)
+k_cluster_verify_w(const uint32_t* members, const uint32_t* cl_first, const float4* fit_pt, const float4* fit_nrm,
+                   unsigned n_cl, float th_angle, ClusterRec* rec)
+{
+  __shared__ float s_v[4][kVTile];
+  __shared__ unsigned char s_side[kVTile];
+  const unsigned c = blockIdx.x;
+  if (c >= n_cl) return;
+  const int lane = threadIdx.x;
+  const uint32_t* m = members + cl_first[c];
+  const int sz = rec[c].size;
+
+  // ---- pass 1: sum z (lane 0), sum nx, ny, |nz| (lanes 1..3); bbox in parallel ------------
+  float acc = 0.f;
+  unsigned ct = 0;
+  float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+  for (int base = 0; base < sz; base += kVTile) {
+    const int tile = min(kVTile, sz - base);
+    for (int t = lane; t < tile; t += kWave) {
+      const unsigned g = m[base + t];
+      const float4 p = fit_pt[g];
+      const float4 nn = fit_nrm[g];
+      s_v[0][t] = p.z;
+      s_v[1][t] = nn.x;
+      s_v[2][t] = nn.y;
+      s_v[3][t] = fabsf(nn.z);
+      mnx = fminf(mnx, p.x);
+      mny = fminf(mny, p.y);
+      mxx = fmaxf(mxx, p.x);
+      mxy = fmaxf(mxy, p.y);
+    }
+    __syncthreads();
+    if (lane < 4) {
+      const float* sv = s_v[lane];
+      if (lane == 0) {
+        for (int j = 0; j < tile; ++j) {
+          const float v = sv[j];
+          if (isfinite(v)) {
+            acc += v;
+            ++ct;
+          }
+        }
+      } else {
+#pragma unroll 8
+        for (int j = 0; j < tile; ++j) acc += sv[j];
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    mnx = fminf(mnx, __shfl_xor(mnx, off));
+    mny = fminf(mny, __shfl_xor(mny, off));
+    mxx = fmaxf(mxx, __shfl_xor(mxx, off));
+    mxy = fmaxf(mxy, __shfl_xor(mxy, off));
+  }
+  const float mid = __shfl(acc, 0);
+  const unsigned ctz = (unsigned)__shfl((int)ct, 0);
+  const float s0 = __shfl(acc, 1), s1 = __shfl(acc, 2), s2 = __shfl(acc, 3);
+
+  int pass = 0;
+  if (sz > 2) {
+    const float fsz = (float)sz;
+    const float m0 = s0 / fsz, m1 = s1 / fsz, m2 = s2 / fsz;
+    const float proj_norm = __builtin_sqrtf(m0 * m0 + m1 * m1);
+    const float mean_norm = __builtin_sqrtf(m0 * m0 + (m1 * m1 + m2 * m2));
+    const float grad = hope_det_asinf(proj_norm / mean_norm);
+    if (!(grad > th_angle)) {  // wave-uniform
+      // ---- pass 2: covariance sums cxx, cxy, cyy (lanes 0..2) ---------------------------
+      float cacc = 0.f;
+      for (int base = 0; base < sz; base += kVTile) {
+        const int tile = min(kVTile, sz - base);
+        for (int t = lane; t < tile; t += kWave) {
+          const float4 nn = fit_nrm[m[base + t]];
+          const float tx = nn.x - m0, ty = nn.y - m1;
+          s_v[0][t] = tx * tx;
+          s_v[1][t] = tx * ty;
+          s_v[2][t] = ty * ty;
+        }
+        __syncthreads();
+        if (lane < 3) {
+          const float* sv = s_v[lane];
+#pragma unroll 8
+          for (int j = 0; j < tile; ++j) cacc += sv[j];
+        }
+        __syncthreads();
+      }
+      const float denom = (float)(sz - 1);
+      const float cxx = __shfl(cacc, 0) / denom;
+      const float cxy = __shfl(cacc, 1) / denom;
+      const float cyy = __shfl(cacc, 2) / denom;
+      float ax, ay;
+      principal_axis_2x2(cxx, cxy, cyy, ax, ay);
+      // ---- pass 3: split sums; lanes 0..2 own part 1 (nx, ny, |nz|), lanes 3..5 part 2 ---
+      float pacc = 0.f;
+      unsigned na = 0;
+      const int comp = lane < 3 ? lane : lane - 3;
+      const unsigned char want = lane < 3 ? 1 : 0;
+      for (int base = 0; base < sz; base += kVTile) {
+        const int tile = min(kVTile, sz - base);
+        for (int t = lane; t < tile; t += kWave) {
+          const float4 nn = fit_nrm[m[base + t]];
+          const float tx = nn.x - m0, ty = nn.y - m1;
+          const bool side = (ax * tx + ay * ty > 0.f);
+          s_v[0][t] = nn.x;
+          s_v[1][t] = nn.y;
+          s_v[2][t] = fabsf(nn.z);
+          s_side[t] = side ? 1 : 0;
+          na += side ? 1u : 0u;
+        }
+        __syncthreads();
+        if (lane < 6) {
+          const float* sv = s_v[comp];
+          for (int j = 0; j < tile; ++j)
+            if (s_side[j] == want) pacc += sv[j];
+        }
+        __syncthreads();
+      }
+#pragma unroll
+      for (int off = kWave / 2; off > 0; off >>= 1) na += (unsigned)__shfl_xor((int)na, off);
+      const unsigned nb = (unsigned)sz - na;
+      if (na != 0 && nb != 0) {
+        const float fa = (float)na, fb = (float)nb;
+        const float p1[3] = {__shfl(pacc, 0) / fa, __shfl(pacc, 1) / fa, __shfl(pacc, 2) / fa};
+        const float p2[3] = {__shfl(pacc, 3) / fb, __shfl(pacc, 4) / fb, __shfl(pacc, 5) / fb};
+        const float mu = p2[0] * p1[0] + (p2[1] * p1[1] + p2[2] * p1[2]);
+        const float n1 = __builtin_sqrtf(sqnorm3(p1));
+        const float n2 = __builtin_sqrtf(sqnorm3(p2));
+        const float rad_mu = hope_det_acosf(mu / (n1 * n2));
+        pass = (rad_mu <= th_angle) ? 1 : 0;
+      }
+    }
+  }
+  if (lane == 0) {
+    rec[c].z_mean = mid / (float)ctz;
+    rec[c].min_x = mnx;
+    rec[c].min_y = mny;
+    rec[c].max_x = mxx;
+    rec[c].max_y = mxy;
+    rec[c].pass = pass;
+  }
 }
 
 // ---- on-demand export of the transformed cloud (hope_get_transformed) -------------------
