@@ -293,6 +293,54 @@ void rt_post(hope_ctx* c)
   }
 }
 
+inline bool depth8_ok(const DepthSrc& s)
+{
+  return (s.w % 8) == 0 && (reinterpret_cast<uintptr_t>(s.depth) % 16) == 0;
+}
+inline bool depth8_ok(const CloudSrc&) { return false; }
+
+template <class VK>
+void launch_voxel_keys(hope_ctx* c, const DepthSrc& src, size_t n_per_frame, int cell_bits, VK* k_in, uint32_t* v_in)
+{
+  const int F = c->n_frames;
+  if (depth8_ok(src)) {
+    const unsigned bx = std::max(1u, std::min<unsigned>(nblk(n_per_frame / 8), 1024u));
+    hipLaunchKernelGGL((k_voxel_keys_depth8<VK>), dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi, c->inv_xy,
+                       c->inv_z, cell_bits, F, k_in, v_in);
+  } else {
+    const unsigned bx = std::min<unsigned>(nblk(n_per_frame), 4096u);
+    hipLaunchKernelGGL((k_voxel_keys<DepthSrc, VK>), dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi,
+                       c->inv_xy, c->inv_z, cell_bits, F, k_in, v_in);
+  }
+}
+
+template <class VK>
+void launch_voxel_keys(hope_ctx* c, const CloudSrc& src, size_t n_per_frame, int cell_bits, VK* k_in, uint32_t* v_in)
+{
+  const int F = c->n_frames;
+  const unsigned bx = std::min<unsigned>(nblk(n_per_frame), 4096u);
+  hipLaunchKernelGGL((k_voxel_keys<CloudSrc, VK>), dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi, c->inv_xy,
+                     c->inv_z, cell_bits, F, k_in, v_in);
+}
+
+inline void launch_bbox(hope_ctx* c, const DepthSrc& src, size_t n_per_frame)
+{
+  const int F = c->n_frames;
+  if (depth8_ok(src)) {
+    const unsigned bx = std::max(1u, std::min<unsigned>(nblk(n_per_frame / 8), 256u));
+    hipLaunchKernelGGL(k_bbox_depth8, dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi);
+  } else {
+    const unsigned bx = std::max(1u, std::min<unsigned>(nblk(n_per_frame, kBlock * 8), 2048u));
+    hipLaunchKernelGGL((k_bbox<DepthSrc>), dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi);
+  }
+}
+
+inline void launch_bbox(hope_ctx* c, const CloudSrc& src, size_t n_per_frame)
+{
+  const unsigned bx = std::max(1u, std::min<unsigned>(nblk(n_per_frame, kBlock * 8), 2048u));
+  hipLaunchKernelGGL((k_bbox<CloudSrc>), dim3(bx, c->n_frames), dim3(kBlock), 0, c->stream, src, c->d_fi);
+}
+
 template <class Src, class VK>
 int stage_voxel(hope_ctx* c, const Src& src, size_t n_per_frame, int cell_bits, int total_bits, float4*& d_vox,
                 int*& d_vox_frame)
@@ -307,10 +355,8 @@ int stage_voxel(hope_ctx* c, const Src& src, size_t n_per_frame, int cell_bits, 
   ALLOC(k_out, VK, N);
   ALLOC(v_in, uint32_t, N);
   ALLOC(v_out, uint32_t, N);
-  const unsigned bx = std::min<unsigned>(nblk(n_per_frame), 4096u);
   size_t pm = prof_mark(c);
-  hipLaunchKernelGGL((k_voxel_keys<Src, VK>), dim3(bx, F), dim3(kBlock), 0, s, src, c->d_fi, c->inv_xy, c->inv_z,
-                     cell_bits, F, k_in, v_in);
+  launch_voxel_keys<VK>(c, src, n_per_frame, cell_bits, k_in, v_in);
   prof_close(c, ST_VKEYS, pm);
   pm = prof_mark(c);
   if (sizeof(VK) == 4) {
@@ -580,14 +626,13 @@ int run_pipeline(hope_ctx* c, const Src& src, size_t n_per_frame)
 
   // ---- A1..A3 + bbox ------------------------------------------------------------------
   if (n_per_frame > 0) {
-    const unsigned bx = std::max(1u, std::min<unsigned>(nblk(n_per_frame, kBlock * 8), 2048u));
     size_t pm = prof_mark(c);
-    hipLaunchKernelGGL((k_bbox<Src>), dim3(bx, F), dim3(kBlock), 0, s, src, d_fi);
+    launch_bbox(c, src, n_per_frame);
     prof_close(c, ST_BBOX, pm);
   }
   {
     size_t pm = prof_mark(c);
-    hipLaunchKernelGGL(k_frame_grid, dim3(1), dim3(64), 0, s, d_fi, F, c->inv_xy, c->inv_z, c->d_glob);
+    hipLaunchKernelGGL(k_frame_grid, dim3(1), dim3(1024), 0, s, d_fi, F, c->inv_xy, c->inv_z, c->d_glob);
     prof_close(c, ST_GRID, pm);
   }
   int st = sync_globals(c);

@@ -186,52 +186,85 @@ __global__ void __launch_bounds__(kBlock) k_bbox(Src src, FrameInfo* fi)
 }
 
 // ---- K2: VoxelGrid grid set-up per frame (PCL 1.8.1 voxel_grid.hpp applyFilter) -------
-__global__ void k_frame_grid(FrameInfo* fi, int n_frames, float inv_xy, float inv_z, Globals* g)
+__global__ void __launch_bounds__(1024) k_frame_grid(FrameInfo* fi, int n_frames, float inv_xy, float inv_z, Globals* g)
 {
-  // one thread: the per-frame prefix over column-table sizes is sequential and tiny
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  unsigned col_off = 0;
-  unsigned long long max_cells = 1;
-  unsigned max_dz = 1, any_over = 0;
-  for (int f = 0; f < n_frames; ++f) {
-    FrameInfo& F = fi[f];
-    F.col_off = (int)col_off;
-    F.overflow = 0;
-    F.cells = 0;
-    F.slack = 0.f;
-    for (int d = 0; d < 3; ++d) F.min_b[d] = F.div_b[d] = 0;
-    if (F.n_raw <= 0) {
-      col_off += 1;
-      continue;
-    }
-    const float inv[3] = {inv_xy, inv_xy, inv_z};
-    long long dxyz = 1;
-    float maxabs = 0.f;
-    for (int d = 0; d < 3; ++d) {
-      const float mn = ord2f(F.bb_min[d]), mx = ord2f(F.bb_max[d]);
-      dxyz *= (long long)((mx - mn) * inv[d]) + 1;
-      F.min_b[d] = (int)floorf(mn * inv[d]);
-      const int max_b = (int)floorf(mx * inv[d]);
-      F.div_b[d] = max_b - F.min_b[d] + 1;
-      if (d < 2) maxabs = fmaxf(maxabs, fmaxf(fabsf(mn), fabsf(mx)) * inv[d]);
-    }
-    if (dxyz > 2147483647LL) {
-      F.overflow = 1;
-      any_over = 1;
-      col_off += 1;
-      continue;
-    }
-    F.cells = (long long)F.div_b[0] * F.div_b[1] * F.div_b[2];
-    // |fl(x*inv) - x*inv| <= 2^-24 * |x*inv|; two such errors enter a column difference
-    F.slack = maxabs * 2.4e-7f + 1e-6f;
-    if ((unsigned long long)F.cells > max_cells) max_cells = (unsigned long long)F.cells;
-    if ((unsigned)F.div_b[2] > max_dz) max_dz = (unsigned)F.div_b[2];
-    col_off += (unsigned)(F.div_b[0] * F.div_b[1]) + 1u;
+  // one 1024-thread block: per-frame grid set-up in parallel, then a block-wide exclusive
+  // scan of the per-frame column-table sizes
+  __shared__ unsigned s_scan[1024];
+  __shared__ unsigned long long s_max_cells;
+  __shared__ unsigned s_max_dz, s_any_over, s_carry;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    s_max_cells = 1;
+    s_max_dz = 1;
+    s_any_over = 0;
+    s_carry = 0;
   }
-  g->max_cells = max_cells;
-  g->total_cols = col_off;
-  g->max_div_z = max_dz;
-  g->any_overflow = any_over;
+  __syncthreads();
+  for (int base = 0; base < n_frames; base += 1024) {
+    const int f = base + tid;
+    unsigned ncols = 0;
+    if (f < n_frames) {
+      FrameInfo& F = fi[f];
+      int min_b[3] = {0, 0, 0}, div_b[3] = {0, 0, 0};
+      int overflow = 0;
+      long long cells = 0;
+      float slack = 0.f;
+      ncols = 1;
+      if (F.n_raw > 0) {
+        const float inv[3] = {inv_xy, inv_xy, inv_z};
+        long long dxyz = 1;
+        float maxabs = 0.f;
+        for (int d = 0; d < 3; ++d) {
+          const float mn = ord2f(F.bb_min[d]), mx = ord2f(F.bb_max[d]);
+          dxyz *= (long long)((mx - mn) * inv[d]) + 1;
+          min_b[d] = (int)floorf(mn * inv[d]);
+          const int max_b = (int)floorf(mx * inv[d]);
+          div_b[d] = max_b - min_b[d] + 1;
+          if (d < 2) maxabs = fmaxf(maxabs, fmaxf(fabsf(mn), fabsf(mx)) * inv[d]);
+        }
+        if (dxyz > 2147483647LL) {
+          overflow = 1;
+          atomicOr(&s_any_over, 1u);
+          for (int d = 0; d < 3; ++d) min_b[d] = div_b[d] = 0;
+        } else {
+          cells = (long long)div_b[0] * div_b[1] * div_b[2];
+          // |fl(x*inv) - x*inv| <= 2^-24 * |x*inv|; two such errors enter a column difference
+          slack = maxabs * 2.4e-7f + 1e-6f;
+          atomicMax(&s_max_cells, (unsigned long long)cells);
+          atomicMax(&s_max_dz, (unsigned)div_b[2]);
+          ncols = (unsigned)(div_b[0] * div_b[1]) + 1u;
+        }
+      }
+      for (int d = 0; d < 3; ++d) {
+        F.min_b[d] = min_b[d];
+        F.div_b[d] = div_b[d];
+      }
+      F.overflow = overflow;
+      F.cells = cells;
+      F.slack = slack;
+    }
+    // inclusive Hillis-Steele scan of ncols over the chunk
+    s_scan[tid] = ncols;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const unsigned add = tid >= off ? s_scan[tid - off] : 0u;
+      __syncthreads();
+      s_scan[tid] += add;
+      __syncthreads();
+    }
+    const unsigned carry = s_carry;
+    if (f < n_frames) fi[f].col_off = (int)(carry + s_scan[tid] - ncols);
+    __syncthreads();
+    if (tid == 1023) s_carry = carry + s_scan[1023];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    g->max_cells = s_max_cells;
+    g->total_cols = s_carry;
+    g->max_div_z = s_max_dz;
+    g->any_overflow = s_any_over;
+  }
 }
 
 // ---- K3: voxel keys -------------------------------------------------------------------
@@ -258,6 +291,115 @@ k_voxel_keys(Src src, const FrameInfo* fi, float inv_xy, float inv_z, int cell_b
     const size_t o = (size_t)frame * n + i;
     keys[o] = key;
     vals[o] = (uint32_t)o;
+  }
+}
+
+// ---- depth-frame fast paths: 8 pixels (one 16-byte load) per thread ----------------------
+// Same arithmetic as load_point(DepthSrc); requires w % 8 == 0 and a 16-byte aligned buffer.
+struct Px8 {
+  float x[8], y[8], z[8];
+  unsigned valid;  // bit j set: pixel j survives A1/A2
+};
+
+__device__ __forceinline__ void load_px8(const DepthSrc& s, const float* aff, int frame, unsigned p0, Px8& o)
+{
+  const uint4 raw = *reinterpret_cast<const uint4*>(s.depth + (size_t)frame * s.ppf + p0);
+  const unsigned wds[4] = {raw.x, raw.y, raw.z, raw.w};
+  const int row = (int)(p0 / (unsigned)s.w);
+  const int col0 = (int)(p0 - (unsigned)row * (unsigned)s.w);
+  const float fr = (float)row - s.cy;
+  o.valid = 0u;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const unsigned d = (wds[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+    const float z = (float)d / s.scale;
+    if (z < s.max_d && z > s.min_d) {
+      const float x = ((float)(col0 + j) - s.cx) * z / s.fx;
+      const float y = fr * z / s.fy;
+      apply_affine(aff, x, y, z, o.x[j], o.y[j], o.z[j]);
+      o.valid |= 1u << j;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_bbox_depth8(DepthSrc src, FrameInfo* fi)
+{
+  const int frame = blockIdx.y;
+  const unsigned n8 = src.ppf / 8;
+  const float* aff = fi[frame].aff;
+  float mn[3] = {INFINITY, INFINITY, INFINITY};
+  float mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  int cnt = 0;
+  for (unsigned t = blockIdx.x * kBlock + threadIdx.x; t < n8; t += gridDim.x * kBlock) {
+    Px8 p;
+    load_px8(src, aff, frame, t * 8, p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (p.valid & (1u << j)) {
+        mn[0] = fminf(mn[0], p.x[j]);
+        mn[1] = fminf(mn[1], p.y[j]);
+        mn[2] = fminf(mn[2], p.z[j]);
+        mx[0] = fmaxf(mx[0], p.x[j]);
+        mx[1] = fmaxf(mx[1], p.y[j]);
+        mx[2] = fmaxf(mx[2], p.z[j]);
+      }
+    }
+    cnt += __popc(p.valid);
+  }
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      mn[d] = fminf(mn[d], __shfl_down(mn[d], off));
+      mx[d] = fmaxf(mx[d], __shfl_down(mx[d], off));
+    }
+    cnt += __shfl_down(cnt, off);
+  }
+  if ((threadIdx.x & (kWave - 1)) == 0 && cnt > 0) {
+    for (int d = 0; d < 3; ++d) {
+      atomicMin(&fi[frame].bb_min[d], f2ord(mn[d]));
+      atomicMax(&fi[frame].bb_max[d], f2ord(mx[d]));
+    }
+    atomicAdd(&fi[frame].n_raw, cnt);
+  }
+}
+
+template <class KeyT>
+__global__ void __launch_bounds__(kBlock)
+k_voxel_keys_depth8(DepthSrc src, const FrameInfo* fi, float inv_xy, float inv_z, int cell_bits, int n_frames,
+                    KeyT* keys, uint32_t* vals)
+{
+  const int frame = blockIdx.y;
+  const unsigned n8 = src.ppf / 8;
+  const FrameInfo& F = fi[frame];
+  const float* aff = F.aff;
+  const int mb0 = F.min_b[0], mb1 = F.min_b[1], mb2 = F.min_b[2];
+  const int d0 = F.div_b[0], d01 = F.div_b[0] * F.div_b[1];
+  const KeyT sentinel = (KeyT)n_frames << cell_bits;
+  const KeyT fbits = (KeyT)frame << cell_bits;
+  const bool over = F.overflow != 0;
+  for (unsigned t = blockIdx.x * kBlock + threadIdx.x; t < n8; t += gridDim.x * kBlock) {
+    Px8 p;
+    load_px8(src, aff, frame, t * 8, p);
+    const size_t o = (size_t)frame * src.ppf + (size_t)t * 8;
+    KeyT k[8];
+    uint32_t v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      k[j] = sentinel;
+      if (!over && (p.valid & (1u << j))) {
+        const int i0 = (int)(floorf(p.x[j] * inv_xy) - (float)mb0);
+        const int i1 = (int)(floorf(p.y[j] * inv_xy) - (float)mb1);
+        const int i2 = (int)(floorf(p.z[j] * inv_z) - (float)mb2);
+        k[j] = fbits | (KeyT)(unsigned)(i0 + i1 * d0 + i2 * d01);
+      }
+      v[j] = (uint32_t)(o + j);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) keys[o + j] = k[j];
+    uint4* vp = reinterpret_cast<uint4*>(vals + o);
+    vp[0] = make_uint4(v[0], v[1], v[2], v[3]);
+    vp[1] = make_uint4(v[4], v[5], v[6], v[7]);
   }
 }
 
@@ -327,6 +469,38 @@ k_centroids(Src src, const FrameInfo* fi, const KeyT* unique, const uint32_t* ru
 constexpr int kR = 16;          // entries per voxel per round
 constexpr int kRStride = 65;    // LDS row stride (dwords): conflict-free reads, <=4-way writes
 
+// one round of the load phase; UNI: every voxel of the wave lies in frame f0, so the pose is
+// fetched with scalar loads.  Branch-free (clamped indices) so that all 16 index loads and all
+// 16 depth gathers of a round are in flight together.
+template <bool UNI, class Src>
+__device__ __forceinline__ void centroid_load_round(const Src& src, const FrameInfo* fi, const uint32_t* vals_sorted,
+                                                    unsigned n, unsigned r0, int f0, int frame, unsigned my_start,
+                                                    unsigned my_cnt, int sub, int grp, float* s_x, float* s_y,
+                                                    float* s_z)
+{
+  unsigned o[kR];
+  int fv[kR];
+#pragma unroll
+  for (int q = 0; q < kR; ++q) {
+    const int vl = q * (kWave / kR) + grp;
+    const unsigned cnt_v = (unsigned)__shfl((int)my_cnt, vl);
+    const unsigned start_v = (unsigned)__shfl((int)my_start, vl);
+    fv[q] = UNI ? f0 : __shfl(frame, vl);
+    const unsigned e = min(r0 + (unsigned)sub, cnt_v > 0u ? cnt_v - 1u : 0u);
+    o[q] = vals_sorted[start_v + e];
+  }
+#pragma unroll
+  for (int q = 0; q < kR; ++q) {
+    const int vl = q * (kWave / kR) + grp;
+    const unsigned i = o[q] - (unsigned)((size_t)fv[q] * n);
+    float x = 0.f, y = 0.f, z = 0.f;
+    load_point(src, fi, fv[q], i < n ? i : 0u, x, y, z);
+    s_x[sub * kRStride + vl] = x;
+    s_y[sub * kRStride + vl] = y;
+    s_z[sub * kRStride + vl] = z;
+  }
+}
+
 template <class Src, class KeyT>
 __global__ void __launch_bounds__(kWave)
 k_centroids_w(Src src, const FrameInfo* fi, const KeyT* unique, const uint32_t* run_start, const uint32_t* run_count,
@@ -343,26 +517,16 @@ k_centroids_w(Src src, const FrameInfo* fi, const KeyT* unique, const uint32_t* 
   unsigned max_cnt = my_cnt;
 #pragma unroll
   for (int off = kWave / 2; off > 0; off >>= 1) max_cnt = max(max_cnt, (unsigned)__shfl_xor((int)max_cnt, off));
+  const int f0 = __builtin_amdgcn_readfirstlane(frame);
+  const bool uni = __all(!live || frame == f0) != 0;
   float sx = 0.f, sy = 0.f, sz = 0.f;
   const int sub = lane & (kR - 1);   // entry within the round
   const int grp = lane / kR;         // which of the 4 voxels this load serves
   for (unsigned r0 = 0; r0 < max_cnt; r0 += kR) {
-#pragma unroll 4
-    for (int q = 0; q < kWave / (kWave / kR); ++q) {
-      const int vl = q * (kWave / kR) + grp;
-      const unsigned cnt_v = (unsigned)__shfl((int)my_cnt, vl);
-      const unsigned start_v = (unsigned)__shfl((int)my_start, vl);
-      const int frame_v = __shfl(frame, vl);
-      const unsigned e = r0 + sub;
-      if (e < cnt_v) {
-        const unsigned i = (unsigned)(vals_sorted[start_v + e] - (unsigned)((size_t)frame_v * n));
-        float x, y, z;
-        load_point(src, fi, frame_v, i, x, y, z);
-        s_x[sub * kRStride + vl] = x;
-        s_y[sub * kRStride + vl] = y;
-        s_z[sub * kRStride + vl] = z;
-      }
-    }
+    if (uni)
+      centroid_load_round<true>(src, fi, vals_sorted, n, r0, f0, frame, my_start, my_cnt, sub, grp, s_x, s_y, s_z);
+    else
+      centroid_load_round<false>(src, fi, vals_sorted, n, r0, f0, frame, my_start, my_cnt, sub, grp, s_x, s_y, s_z);
     __syncthreads();
     const int k = (int)min((unsigned)kR, my_cnt > r0 ? my_cnt - r0 : 0u);
     for (int j = 0; j < k; ++j) {
