@@ -26,25 +26,9 @@ if ROOT not in sys.path:
 W, H = 640, 480
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
-# ALGORITHMIC bytes per unit for each timed stage (DESIGN.md "Kernels and rooflines";
-# SURVEY.md §8d).  unit: px = input pixel, vox = down-sampled point, fit = normal-filtered point
-STAGE_BYTES = {
-    "k_bbox": ("px", 2.0),                       # read u16 depth
-    "k_frame_grid": ("frame", 176.0),            # per-frame state record
-    "k_voxel_keys": ("px", 2.0 + 8.0),           # read depth, write (key u32, index u32)
-    "voxel_sort(rocprim)": ("px", 16.0),         # pairs read once + written once
-    "voxel_rle+scan(rocprim)": ("px", 4.0),      # sorted keys read once
-    "k_centroids": ("px", 4.0 + 2.0),            # sorted index + depth re-read (+16 B / voxel out)
-    "k_column_keys": ("vox", 16.0 + 8.0),
-    "column_sort(rocprim)": ("vox", 16.0),
-    "k_column_table+gather": ("vox", 4.0 + 16.0 + 16.0),
-    "k_normals": ("vox", 16.0 + 16.0),           # A6: point in, normal out
-    "fit_gate+compact": ("vox", 16.0 + 4.0 + 4.0),
-    "k_knn": ("fit", 16.0 + 32.0),               # A8: point in, 8 neighbours out
-    "labels(union+sweeps)": ("fit", 32.0 + 4.0 + 4.0),  # A9
-    "segments(scan+sort)": ("fit", 16.0),
-    "k_cluster_verify": ("fit", 4.0 + 16.0 + 16.0),     # A10-A12
-}
+# The ALGORITHMIC bytes of every timed stage are accounted by the library
+# itself from the sizes of each call (hope_profile_stage_bytes), next to the HIP-event time of
+# the same region on the library's own stream.
 
 
 def parse_args():
@@ -53,7 +37,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=1024, help="depth frames per GPU per step")
-    ap.add_argument("--cpu-frames", type=int, default=128, help="frames timed through the CPU oracle")
+    ap.add_argument("--cpu-frames", type=int, default=512, help="frames timed through the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -155,20 +139,18 @@ def main():
 
     if rank == 0:
         prof = ctx.profile()
-        units = {"px": F * W * H, "vox": n_vox, "fit": n_fit, "frame": F}
         stages = []
-        for name, ms, launches in prof:
-            if launches == 0:
+        for name, ms, regions, alg_bytes in prof:
+            if regions == 0:
                 continue
             per_step_ms = ms / args.steps
-            unit, bpu = STAGE_BYTES[name]
-            gbs = bpu * units[unit] / (per_step_ms * 1e-3) / 1e9 if per_step_ms > 0 else 0.0
+            gbs = alg_bytes / args.steps / (per_step_ms * 1e-3) / 1e9 if per_step_ms > 0 else 0.0
             stages.append({"stage": name, "ms_per_step": round(per_step_ms, 4),
-                           "launches_per_step": launches / args.steps,
-                           "alg_bytes_per_unit": bpu, "unit": unit, "achieved_GBs": round(gbs, 1)})
+                           "timed_regions_per_step": regions / args.steps,
+                           "alg_bytes_per_step": alg_bytes / args.steps, "achieved_GBs": round(gbs, 1)})
         dom = max(stages, key=lambda s: s["ms_per_step"])
-        dom_launch_ms = dom["ms_per_step"] / dom["launches_per_step"]
-        dom_bytes = STAGE_BYTES[dom["stage"]][1] * units[STAGE_BYTES[dom["stage"]][0]] / dom["launches_per_step"]
+        dom_launch_ms = dom["ms_per_step"] / dom["timed_regions_per_step"]
+        dom_bytes = dom["alg_bytes_per_step"] / dom["timed_regions_per_step"]
         achieved = dom_bytes / (dom_launch_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")

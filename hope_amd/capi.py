@@ -133,6 +133,10 @@ class HopeLib:
             f.restype = C.c_int
             f.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
             self.fn["profile_stage"] = f
+            f = getattr(self.dll, prefix + "profile_stage_bytes")
+            f.restype = C.c_int
+            f.argtypes = [vp, i32, C.POINTER(C.c_double)]
+            self.fn["profile_stage_bytes"] = f
 
     def default_config(self):
         cfg = HopeConfig()
@@ -296,12 +300,14 @@ class HopeContext:
         self._check(self.lib.fn["profile_enable"](self._h, 1 if on else 0), "profile_enable")
 
     def profile(self):
-        """[(stage name, total device ms, launches)] accumulated since profile_enable()."""
+        """[(stage name, total device ms, timed regions, algorithmic bytes)] accumulated since
+        profile_enable()."""
         out = []
         for i in range(self.lib.fn["profile_stage_count"]()):
-            name, ms, n = C.c_char_p(), C.c_double(), C.c_int64()
+            name, ms, n, by = C.c_char_p(), C.c_double(), C.c_int64(), C.c_double()
             self.lib.fn["profile_stage"](self._h, i, C.byref(name), C.byref(ms), C.byref(n))
-            out.append((name.value.decode(), ms.value, n.value))
+            self.lib.fn["profile_stage_bytes"](self._h, i, C.byref(by))
+            out.append((name.value.decode(), ms.value, n.value, by.value))
         return out
 
     def timing(self):

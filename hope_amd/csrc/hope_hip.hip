@@ -101,9 +101,11 @@ struct Prof {
   struct Rec {
     int st;
     size_t a, b;
+    double bytes;
   };
   std::vector<Rec> recs;
   double ms[ST_COUNT] = {};
+  double bytes[ST_COUNT] = {};  // algorithmic bytes of the closed regions
   long long launches[ST_COUNT] = {};
 };
 
@@ -125,6 +127,10 @@ struct hope_ctx {
   std::string err;
   double whole_ms = 0, ref_ms = 0;
   int normals_cap_small = 0;  // test knob: force the neighbour-list overflow path
+  int pixel_sort = 0;         // test knob: depth frames through the per-pixel sort (the cloud path's voxel stage)
+  uint32_t* d_grp_cnt = nullptr;  // depth path: groups per chunk, then its exclusive scan
+  uint32_t* d_grp_off = nullptr;
+  unsigned cpf = 0;               // chunks per frame
   Prof prof;
 
   // ---- state of the last call --------------------------------------------------------
@@ -230,11 +236,11 @@ size_t prof_mark(hope_ctx* c)
   return p.used++;
 }
 
-void prof_close(hope_ctx* c, int st, size_t a)
+void prof_close(hope_ctx* c, int st, size_t a, double alg_bytes = 0.0)
 {
   if (!c->prof.on) return;
   const size_t b = prof_mark(c);
-  c->prof.recs.push_back(Prof::Rec{st, a, b});
+  c->prof.recs.push_back(Prof::Rec{st, a, b, alg_bytes});
 }
 
 void prof_collect(hope_ctx* c)  // call after the stream has been synchronised
@@ -244,6 +250,7 @@ void prof_collect(hope_ctx* c)  // call after the stream has been synchronised
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, p.ev[r.a], p.ev[r.b]) == hipSuccess) {
       p.ms[r.st] += ms;
+      p.bytes[r.st] += r.bytes;
       p.launches[r.st] += 1;
     }
   }
@@ -323,24 +330,80 @@ void launch_voxel_keys(hope_ctx* c, const CloudSrc& src, size_t n_per_frame, int
                      c->inv_z, cell_bits, F, k_in, v_in);
 }
 
-inline void launch_bbox(hope_ctx* c, const DepthSrc& src, size_t n_per_frame)
+inline bool use_groups(const hope_ctx* c, const DepthSrc&) { return !c->pixel_sort; }
+inline bool use_groups(const hope_ctx*, const CloudSrc&) { return false; }
+
+inline int launch_bbox(hope_ctx* c, const DepthSrc& src, size_t n_per_frame)
 {
   const int F = c->n_frames;
-  if (depth8_ok(src)) {
+  if (use_groups(c, src)) {
+    c->cpf = (unsigned)((n_per_frame + kChunk - 1) / kChunk);
+    const size_t n_chunks = (size_t)c->cpf * F;
+    ALLOC(c->d_grp_cnt, uint32_t, n_chunks + 1);
+    ALLOC(c->d_grp_off, uint32_t, n_chunks + 1);
+    HIPCHK(hipMemsetAsync(c->d_grp_cnt + n_chunks, 0, sizeof(uint32_t), c->stream));
+    const unsigned bx = std::max(1u, std::min<unsigned>(nblk(c->cpf, (kBlock / kWave) * 16), 512u));
+    hipLaunchKernelGGL(k_bbox_groups, dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi, c->inv_xy, c->inv_z,
+                       c->cpf, c->d_grp_cnt);
+  } else if (depth8_ok(src)) {
     const unsigned bx = std::max(1u, std::min<unsigned>(nblk(n_per_frame / 8), 256u));
     hipLaunchKernelGGL(k_bbox_depth8, dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi);
   } else {
     const unsigned bx = std::max(1u, std::min<unsigned>(nblk(n_per_frame, kBlock * 8), 2048u));
     hipLaunchKernelGGL((k_bbox<DepthSrc>), dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi);
   }
+  return HOPE_OK;
 }
 
-inline void launch_bbox(hope_ctx* c, const CloudSrc& src, size_t n_per_frame)
+// depth path: exclusive scan of the per-chunk group counts; the total lands in Globals
+inline int scan_groups(hope_ctx* c, const DepthSrc& src, size_t n_per_frame)
+{
+  if (!use_groups(c, src) || n_per_frame == 0) return HOPE_OK;
+  PrimAlloc pa{arena_alloc_cb, &c->arena};
+  const size_t n_chunks = (size_t)c->cpf * c->n_frames;
+  HIPCHK(exclusive_scan_u32(pa, c->d_grp_cnt, c->d_grp_off, n_chunks + 1, c->stream));
+  HIPCHK(hipMemcpyAsync(&c->d_glob->n_groups, c->d_grp_off + n_chunks, sizeof(uint32_t), hipMemcpyDeviceToDevice,
+                        c->stream));
+  return HOPE_OK;
+}
+inline int scan_groups(hope_ctx*, const CloudSrc&, size_t) { return HOPE_OK; }
+
+inline int launch_bbox(hope_ctx* c, const CloudSrc& src, size_t n_per_frame)
 {
   const unsigned bx = std::max(1u, std::min<unsigned>(nblk(n_per_frame, kBlock * 8), 2048u));
   hipLaunchKernelGGL((k_bbox<CloudSrc>), dim3(bx, c->n_frames), dim3(kBlock), 0, c->stream, src, c->d_fi);
+  return HOPE_OK;
 }
 
+template <class VK>
+void launch_group_records(hope_ctx* c, const DepthSrc& src, unsigned bx, int cell_bits, VK* rkey, uint32_t* rval,
+                          uint4* rec)
+{
+  hipLaunchKernelGGL((k_group_records<VK>), dim3(bx, c->n_frames), dim3(kBlock), 0, c->stream, src, c->d_fi,
+                     c->inv_xy, c->inv_z, cell_bits, c->cpf, c->d_grp_off, rkey, rval, rec);
+}
+template <class VK>
+void launch_group_records(hope_ctx*, const CloudSrc&, unsigned, int, VK*, uint32_t*, uint4*) {}
+
+template <class VK>
+void launch_centroids_groups(hope_ctx* c, const DepthSrc& src, const VK* uniq, const uint32_t* run_start,
+                             const uint32_t* run_cnt, const uint32_t* sval, const uint4* rec, unsigned n_vox,
+                             int cell_bits, float4* d_vox, int* d_vox_frame)
+{
+  hipLaunchKernelGGL((k_centroids_groups<VK>), dim3(nblk(n_vox)), dim3(kBlock), 0, c->stream, src, c->d_fi, uniq,
+                     run_start, run_cnt, sval, rec, n_vox, cell_bits, c->cpf, d_vox, d_vox_frame);
+}
+template <class VK>
+void launch_centroids_groups(hope_ctx*, const CloudSrc&, const VK*, const uint32_t*, const uint32_t*, const uint32_t*,
+                             const uint4*, unsigned, int, float4*, int*) {}
+
+inline double src_point_bytes(const DepthSrc&) { return 2.0; }
+inline double src_point_bytes(const CloudSrc&) { return 12.0; }
+
+// A5.  Two ways to bring the points of a voxel together in ascending source index:
+//  * depth frames: sort one record per (64-pixel chunk, voxel) group (k_bbox_groups has already
+//    counted them, scan_groups placed them);
+//  * point clouds (and depth frames under HOPE_DEBUG_PIXEL_SORT=1): sort one pair per point.
 template <class Src, class VK>
 int stage_voxel(hope_ctx* c, const Src& src, size_t n_per_frame, int cell_bits, int total_bits, float4*& d_vox,
                 int*& d_vox_frame)
@@ -349,36 +412,50 @@ int stage_voxel(hope_ctx* c, const Src& src, size_t n_per_frame, int cell_bits, 
   const size_t N = n_per_frame * (size_t)F;
   hipStream_t s = c->stream;
   PrimAlloc pa{arena_alloc_cb, &c->arena};
+  const bool groups = use_groups(c, src);
+  const size_t M = groups ? (size_t)c->h_glob->n_groups : N;  // records to sort
+  if (M == 0) {
+    c->n_vox_total = 0;
+    return HOPE_OK;
+  }
   VK *k_in, *k_out, *uniq;
   uint32_t *v_in, *v_out, *run_cnt, *run_start;
-  ALLOC(k_in, VK, N);
-  ALLOC(k_out, VK, N);
-  ALLOC(v_in, uint32_t, N);
-  ALLOC(v_out, uint32_t, N);
+  uint4* rec = nullptr;
+  ALLOC(k_in, VK, M);
+  ALLOC(k_out, VK, M);
+  ALLOC(v_in, uint32_t, M);
+  ALLOC(v_out, uint32_t, M);
   size_t pm = prof_mark(c);
-  launch_voxel_keys<VK>(c, src, n_per_frame, cell_bits, k_in, v_in);
-  prof_close(c, ST_VKEYS, pm);
+  if (groups) {
+    ALLOC(rec, uint4, M);
+    const unsigned bx = std::max(1u, std::min<unsigned>(nblk(c->cpf, (kBlock / kWave) * 16), 512u));
+    launch_group_records<VK>(c, src, bx, cell_bits, k_in, v_in, rec);
+    prof_close(c, ST_VKEYS, pm, 2.0 * N + 4.0 * ((double)c->cpf * F) + (sizeof(VK) + 4.0 + 16.0) * M);
+  } else {
+    launch_voxel_keys<VK>(c, src, n_per_frame, cell_bits, k_in, v_in);
+    prof_close(c, ST_VKEYS, pm, (2.0 + sizeof(VK) + 4.0) * N);
+  }
   pm = prof_mark(c);
   if (sizeof(VK) == 4) {
-    HIPCHK(sort_pairs_u32(pa, (const uint32_t*)k_in, (uint32_t*)k_out, v_in, v_out, N, total_bits, s));
+    HIPCHK(sort_pairs_u32(pa, (const uint32_t*)k_in, (uint32_t*)k_out, v_in, v_out, M, total_bits, s));
   } else {
-    HIPCHK(sort_pairs_u64(pa, (const uint64_t*)k_in, (uint64_t*)k_out, v_in, v_out, N, total_bits, s));
+    HIPCHK(sort_pairs_u64(pa, (const uint64_t*)k_in, (uint64_t*)k_out, v_in, v_out, M, total_bits, s));
   }
-  prof_close(c, ST_VSORT, pm);
+  prof_close(c, ST_VSORT, pm, 2.0 * (sizeof(VK) + 4.0) * M);
   pm = prof_mark(c);
   // k_in / v_in are dead now: reuse them for the run-length outputs
   uniq = k_in;
   run_cnt = v_in;
-  ALLOC(run_start, uint32_t, N + 1);
+  ALLOC(run_start, uint32_t, M + 1);
   if (sizeof(VK) == 4) {
-    HIPCHK(rle_u32(pa, (const uint32_t*)k_out, N, (uint32_t*)uniq, run_cnt, &c->d_glob->n_runs, s));
+    HIPCHK(rle_u32(pa, (const uint32_t*)k_out, M, (uint32_t*)uniq, run_cnt, &c->d_glob->n_runs, s));
   } else {
-    HIPCHK(rle_u64(pa, (const uint64_t*)k_out, N, (uint64_t*)uniq, run_cnt, &c->d_glob->n_runs, s));
+    HIPCHK(rle_u64(pa, (const uint64_t*)k_out, M, (uint64_t*)uniq, run_cnt, &c->d_glob->n_runs, s));
   }
   hipLaunchKernelGGL((k_frame_vox_ranges<VK>), dim3(nblk(F + 1)), dim3(kBlock), 0, s, c->d_fi, F, uniq,
                      &c->d_glob->n_runs, cell_bits, c->d_glob);
   hipLaunchKernelGGL(k_frame_vox_counts, dim3(nblk(F)), dim3(kBlock), 0, s, c->d_fi, F, c->d_glob);
-  prof_close(c, ST_VRLE, pm);
+  prof_close(c, ST_VRLE, pm, (double)sizeof(VK) * M);
   int st = sync_globals(c);
   if (st != HOPE_OK) return st;
   const unsigned n_vox = c->h_glob->n_vox_total;
@@ -386,13 +463,18 @@ int stage_voxel(hope_ctx* c, const Src& src, size_t n_per_frame, int cell_bits, 
   if (n_vox == 0) return HOPE_OK;
   pm = prof_mark(c);
   HIPCHK(exclusive_scan_u32(pa, run_cnt, run_start, n_vox, s));
-  prof_close(c, ST_VRLE, pm);
+  prof_close(c, ST_VRLE, pm, 8.0 * n_vox);
   ALLOC(d_vox, float4, n_vox);
   ALLOC(d_vox_frame, int, n_vox);
   pm = prof_mark(c);
-  hipLaunchKernelGGL((k_centroids_w<Src, VK>), dim3(nblk(n_vox, kWave)), dim3(kWave), 0, s, src, c->d_fi, uniq,
-                     run_start, run_cnt, v_out, n_vox, cell_bits, d_vox, d_vox_frame);
-  prof_close(c, ST_CENTROID, pm);
+  if (groups) {
+    launch_centroids_groups<VK>(c, src, uniq, run_start, run_cnt, v_out, rec, n_vox, cell_bits, d_vox, d_vox_frame);
+    prof_close(c, ST_CENTROID, pm, (4.0 + 16.0) * M + 2.0 * N + 28.0 * n_vox);
+  } else {
+    hipLaunchKernelGGL((k_centroids_w<Src, VK>), dim3(nblk(n_vox, kWave)), dim3(kWave), 0, s, src, c->d_fi, uniq,
+                       run_start, run_cnt, v_out, n_vox, cell_bits, d_vox, d_vox_frame);
+    prof_close(c, ST_CENTROID, pm, (4.0 + src_point_bytes(src)) * N + 28.0 * n_vox);
+  }
   return HOPE_OK;
 }
 
@@ -419,19 +501,19 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   size_t pm = prof_mark(c);
   hipLaunchKernelGGL((k_column_keys<CK>), dim3(nblk(n_vox)), dim3(kBlock), 0, s, d_vox, d_vox_frame, c->d_fi,
                      n_vox, c->inv_xy, c->inv_z, zbits, ck_in, cv_in);
-  prof_close(c, ST_COLKEYS, pm);
+  prof_close(c, ST_COLKEYS, pm, (16.0 + 4.0 + sizeof(CK) + 4.0) * n_vox);
   pm = prof_mark(c);
   if (sizeof(CK) == 4) {
     HIPCHK(sort_pairs_u32(pa, (const uint32_t*)ck_in, (uint32_t*)ck_out, cv_in, cv_out, n_vox, key2_bits, s));
   } else {
     HIPCHK(sort_pairs_u64(pa, (const uint64_t*)ck_in, (uint64_t*)ck_out, cv_in, cv_out, n_vox, key2_bits, s));
   }
-  prof_close(c, ST_COLSORT, pm);
+  prof_close(c, ST_COLSORT, pm, 2.0 * (sizeof(CK) + 4.0) * n_vox);
   pm = prof_mark(c);
   hipLaunchKernelGGL((k_column_table<CK>), dim3(nblk((size_t)total_cols + 1)), dim3(kBlock), 0, s, ck_out, n_vox,
                      total_cols, zbits, col_first);
   hipLaunchKernelGGL(k_gather_sorted, dim3(nblk(n_vox)), dim3(kBlock), 0, s, d_vox, cv_out, n_vox, spt);
-  prof_close(c, ST_COLTABLE, pm);
+  prof_close(c, ST_COLTABLE, pm, (4.0 + 16.0 + 16.0) * n_vox + 4.0 * total_cols);
 
   // ---- A6 normals -----------------------------------------------------------------
   float4* d_normals;
@@ -448,7 +530,7 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
                        d_normals);
   }
 
-  prof_close(c, ST_NORMALS, pm);
+  prof_close(c, ST_NORMALS, pm, (16.0 + 16.0) * n_vox);
   // ---- A7 gate + compaction ---------------------------------------------------------
   uint32_t *flags, *fscan;
   ALLOC(flags, uint32_t, (size_t)n_vox + 1);
@@ -458,7 +540,7 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
                      flags);
   HIPCHK(exclusive_scan_u32(pa, flags, fscan, (size_t)n_vox + 1, s));
   hipLaunchKernelGGL(k_frame_fit_ranges, dim3(nblk(F)), dim3(kBlock), 0, s, c->d_fi, F, fscan);
-  prof_close(c, ST_FIT, pm);
+  prof_close(c, ST_FIT, pm, (16.0 + 4.0 + 4.0 + 4.0) * n_vox);
   uint32_t* h_cnt = reinterpret_cast<uint32_t*>(&c->h_glob->pad);
   HIPCHK(hipMemcpyAsync(h_cnt, fscan + n_vox, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
@@ -477,7 +559,7 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   pm = prof_mark(c);
   hipLaunchKernelGGL(k_fit_scatter, dim3(nblk(n_vox)), dim3(kBlock), 0, s, flags, fscan, n_vox, d_vox, d_normals,
                      d_vox_frame, fit_rank, fit_idx, fit_pt, fit_nrm, fit_frame);
-  prof_close(c, ST_FIT, pm);
+  prof_close(c, ST_FIT, pm, (4.0 + 4.0 + 4.0) * n_vox + (2.0 * (16.0 + 16.0) + 4.0 + 4.0 + 4.0) * n_fit);
   if (n_fit == 0) return HOPE_OK;
 
   HIPCHK(hipEventRecord(c->ev_a, s));  // the reference's timer window opens (plane_segment.cpp:157)
@@ -495,7 +577,7 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
                        d_vox_frame, fit_rank, c->d_fi, n_vox, c->inv_xy, c->inv_z, c->cfg.th_xy, zbits, K, knn);
   }
 
-  prof_close(c, ST_KNN, pm);
+  prof_close(c, ST_KNN, pm, 16.0 * n_vox + 4.0 * K * (double)n_fit);
   // ---- A9 region growing as min-rank reachability -----------------------------------
   int *rank, *seed_node, *parent, *L, *root, *label;
   ALLOC(rank, int, n_fit);
@@ -510,14 +592,14 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
                      L);
   hipLaunchKernelGGL(k_union_mutual, dim3(gb), dim3(kBlock), 0, s, knn, fit_pt, n_fit, K, c->cfg.th_z, parent);
   hipLaunchKernelGGL(k_flatten_roots, dim3(gb), dim3(kBlock), 0, s, parent, rank, n_fit, root, L);
-  prof_close(c, ST_LABELS, pm);
+  prof_close(c, ST_LABELS, pm, (4.0 * K + 16.0 + 5 * 4.0) * n_fit);
   for (int iter = 0; iter < 100000; ++iter) {
     pm = prof_mark(c);
     HIPCHK(hipMemsetAsync(&c->d_glob->changed, 0, sizeof(unsigned), s));
     for (int rep = 0; rep < 2; ++rep)
       hipLaunchKernelGGL(k_label_sweep, dim3(gb), dim3(kBlock), 0, s, knn, fit_pt, root, seed_node, n_fit, K,
                          c->cfg.th_z, L, &c->d_glob->changed);
-    prof_close(c, ST_LABELS, pm);
+    prof_close(c, ST_LABELS, pm, 2.0 * (4.0 * K + 16.0 + 4.0 + 4.0) * n_fit);
     int st = sync_globals(c);
     if (st != HOPE_OK) return st;
     if (!c->h_glob->changed) break;
@@ -541,7 +623,7 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   HIPCHK(exclusive_scan_u32(pa, is_cl, scan_cl, (size_t)n_fit + 1, s));
   HIPCHK(exclusive_scan_u32(pa, cl_pts, scan_pts, (size_t)n_fit + 1, s));
   hipLaunchKernelGGL(k_frame_cluster_ranges, dim3(nblk(F)), dim3(kBlock), 0, s, c->d_fi, F, scan_seg, scan_cl);
-  prof_close(c, ST_SEGMENTS, pm);
+  prof_close(c, ST_SEGMENTS, pm, (4.0 + 4.0 + 4.0 + 7 * 4.0) * n_fit);
   HIPCHK(hipMemcpyAsync(h_cnt, scan_cl + n_fit, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   const unsigned n_cl = *h_cnt;
@@ -567,12 +649,12 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
     HIPCHK(sort_pairs_u32(pa, mkey, mkey_s, mval, members, n_fit, bits_for(n_cl), s));
     hipLaunchKernelGGL(k_cluster_heads, dim3(gb), dim3(kBlock), 0, s, cnt, is_cl, scan_cl, scan_pts, seed_node,
                        fit_frame, c->d_fi, n_fit, cl_first, rec);
-    prof_close(c, ST_SEGMENTS, pm);
+    prof_close(c, ST_SEGMENTS, pm, (4.0 + 4.0 + 2 * 8.0 + 2 * 8.0) * n_fit);
     pm = prof_mark(c);
     // ---- A10..A12 -------------------------------------------------------------------
     hipLaunchKernelGGL(k_cluster_verify_w, dim3(n_cl), dim3(kWave), 0, s, members, cl_first, fit_pt, fit_nrm, n_cl,
                        c->th_angle, rec);
-    prof_close(c, ST_VERIFY, pm);
+    prof_close(c, ST_VERIFY, pm, (4.0 + 16.0 + 16.0) * n_fit + 32.0 * n_cl);
     c->h_rec.resize(n_cl);
     HIPCHK(hipMemcpyAsync(c->h_rec.data(), rec, sizeof(ClusterRec) * n_cl, hipMemcpyDeviceToHost, s));
   }
@@ -625,17 +707,23 @@ int run_pipeline(hope_ctx* c, const Src& src, size_t n_per_frame)
   HIPCHK(hipMemsetAsync(c->d_glob, 0, sizeof(Globals), s));
 
   // ---- A1..A3 + bbox ------------------------------------------------------------------
+  int st;
   if (n_per_frame > 0) {
     size_t pm = prof_mark(c);
-    launch_bbox(c, src, n_per_frame);
-    prof_close(c, ST_BBOX, pm);
+    st = launch_bbox(c, src, n_per_frame);
+    if (st != HOPE_OK) return st;
+    prof_close(c, ST_BBOX, pm, src_point_bytes(src) * n_per_frame * F);
   }
   {
     size_t pm = prof_mark(c);
     hipLaunchKernelGGL(k_frame_grid, dim3(1), dim3(1024), 0, s, d_fi, F, c->inv_xy, c->inv_z, c->d_glob);
-    prof_close(c, ST_GRID, pm);
+    prof_close(c, ST_GRID, pm, (double)sizeof(FrameInfo) * F);
+    pm = prof_mark(c);
+    st = scan_groups(c, src, n_per_frame);
+    if (st != HOPE_OK) return st;
+    if (use_groups(c, src)) prof_close(c, ST_VKEYS, pm, 8.0 * ((double)c->cpf * F));
   }
-  int st = sync_globals(c);
+  st = sync_globals(c);
   if (st != HOPE_OK) return st;
   if (c->h_glob->any_overflow) {
     c->err = "VoxelGrid leaf size too small for the input extent (more than INT_MAX cells); "
@@ -741,6 +829,8 @@ HOPE_API int hope_create(const hope_config* cfg, hope_ctx** out)
   }
   const char* knob = std::getenv("HOPE_DEBUG_SMALL_NB_CAP");
   c->normals_cap_small = (knob && knob[0] == '1') ? 1 : 0;
+  knob = std::getenv("HOPE_DEBUG_PIXEL_SORT");
+  c->pixel_sort = (knob && knob[0] == '1') ? 1 : 0;
   *out = c;
   return HOPE_OK;
 }
@@ -1032,6 +1122,7 @@ HOPE_API int hope_profile_enable(hope_ctx* c, int on)
   c->prof.on = on ? 1 : 0;
   for (int i = 0; i < ST_COUNT; ++i) {
     c->prof.ms[i] = 0;
+    c->prof.bytes[i] = 0;
     c->prof.launches[i] = 0;
   }
   return HOPE_OK;
@@ -1045,6 +1136,13 @@ HOPE_API int hope_profile_stage(hope_ctx* c, int stage, const char** name, doubl
   if (name) *name = kStageNames[stage];
   if (total_ms) *total_ms = c->prof.ms[stage];
   if (launches) *launches = c->prof.launches[stage];
+  return HOPE_OK;
+}
+
+HOPE_API int hope_profile_stage_bytes(hope_ctx* c, int stage, double* alg_bytes)
+{
+  if (!c || stage < 0 || stage >= ST_COUNT || !alg_bytes) return HOPE_E_RANGE;
+  *alg_bytes = c->prof.bytes[stage];
   return HOPE_OK;
 }
 

@@ -47,6 +47,7 @@ struct Globals {  // scalars produced on device, read back at the sync points
   unsigned int changed;
   unsigned int n_vox_total;
   unsigned int pad;
+  unsigned int n_groups;  // depth path: number of (chunk, voxel) group records
 };
 
 struct DepthSrc {
@@ -401,6 +402,278 @@ k_voxel_keys_depth8(DepthSrc src, const FrameInfo* fi, float inv_xy, float inv_z
     vp[0] = make_uint4(v[0], v[1], v[2], v[3]);
     vp[1] = make_uint4(v[4], v[5], v[6], v[7]);
   }
+}
+
+// ---- depth-frame voxel stage by (chunk, voxel) groups --------------------------------------
+// A depth image is spatially coherent: the 64 consecutive pixels of a chunk fall into a handful
+// of voxels.  Instead of sorting one (key, index) pair per pixel, the depth path sorts one
+// record per (chunk, voxel) GROUP -- about 5x fewer -- carrying the 64-bit mask of the group's
+// pixels.  Records are emitted in chunk order and the radix sort is stable, so walking a voxel's
+// records in sorted order and each mask from bit 0 upwards visits the voxel's points in
+// ascending pixel index: the same sequential float sum as VoxelGrid's (voxel_grid.hpp).
+constexpr int kChunk = 64;
+
+__device__ __forceinline__ float readlane_f(float v, int lane)
+{
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// v_writelane_b32: put a wave-uniform value into one lane of a VGPR (hipcc has no builtin for
+// it).  VOP3 may read one SGPR only, so the lane select goes through M0 (s_nop: M0 write ->
+// use); the 4-wait-state rule for a VALU-written lane select does not apply to an SALU write.
+__device__ __forceinline__ void writelane_u64(unsigned long long uniform_val, int uniform_lane, int& lo, int& hi)
+{
+  asm("s_mov_b32 m0, %4\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+      : "+v"(lo), "+v"(hi)
+      : "s"((int)(unsigned)uniform_val), "s"((int)(unsigned)(uniform_val >> 32)), "s"(uniform_lane)
+      : "m0");
+}
+
+// A1..A3 with the pose held in registers (same arithmetic as load_point(DepthSrc))
+__device__ __forceinline__ bool depth_point(const DepthSrc& s, const float* aff, int frame, unsigned pix, float& ox,
+                                            float& oy, float& oz)
+{
+  const uint16_t d = s.depth[(size_t)frame * s.ppf + pix];
+  const int row = (int)(pix / (unsigned)s.w);
+  const int col = (int)(pix - (unsigned)row * (unsigned)s.w);
+  const float z = (float)d / s.scale;
+  if (!(z < s.max_d && z > s.min_d)) return false;
+  const float x = ((float)col - s.cx) * z / s.fx;
+  const float y = ((float)row - s.cy) * z / s.fy;
+  apply_affine(aff, x, y, z, ox, oy, oz);
+  return true;
+}
+
+// Groups of one chunk: lanes with equal cell triple (gx, gy, gz).  Returns the number of groups;
+// with MASKS also, per group, the pixel mask in the lane of the group's first pixel (0 elsewhere)
+// and the mask of those first lanes.  Fast path: the triple is packed relative to the chunk's
+// first surviving pixel into 11+11+10 bits, one compare per group; a chunk whose offsets do not
+// fit (a depth jump of more than 51 m / 10 m) compares the three floats.  Both passes call this
+// same function, so their group counts agree by construction.
+template <bool MASKS>
+__device__ __forceinline__ unsigned chunk_groups(bool ok, float gx, float gy, float gz, unsigned long long& my_grp)
+{
+  unsigned long long todo = __ballot(ok);
+  unsigned ng = 0;
+  int g_lo = 0, g_hi = 0;  // this lane's group mask, written by v_writelane from the scalar ballot
+  if (todo) {
+    const int l0 = __ffsll((long long)todo) - 1;
+    const float dx = gx - readlane_f(gx, l0), dy = gy - readlane_f(gy, l0), dz = gz - readlane_f(gz, l0);
+    const bool fit = !ok || (fabsf(dx) < 1023.f && fabsf(dy) < 1023.f && fabsf(dz) < 511.f);
+    if (__all(fit)) {
+      const unsigned code = ok ? ((unsigned)((int)dx + 1024) | ((unsigned)((int)dy + 1024) << 11) |
+                                  ((unsigned)((int)dz + 512) << 22))
+                               : 0xffffffffu;
+      while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const unsigned k = (unsigned)__builtin_amdgcn_readlane((int)code, leader);
+        const unsigned long long grp = __ballot(code == k);
+        if (MASKS) {
+          writelane_u64(grp, leader, g_lo, g_hi);
+        }
+        todo &= ~grp;
+        ++ng;
+      }
+    } else {
+      while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const float lx = readlane_f(gx, leader), ly = readlane_f(gy, leader), lz = readlane_f(gz, leader);
+        const unsigned long long grp = __ballot(ok && gx == lx && gy == ly && gz == lz) | (1ull << leader);
+        if (MASKS) {
+          writelane_u64(grp, leader, g_lo, g_hi);
+        }
+        todo &= ~grp;
+        ++ng;
+      }
+    }
+  }
+  my_grp = (unsigned long long)(unsigned)g_lo | ((unsigned long long)(unsigned)g_hi << 32);
+  return ng;
+}
+
+// row / column of the 64 pixels of a chunk without a per-lane integer division
+__device__ __forceinline__ void chunk_rowcol(unsigned c, int lane, unsigned w, int& row, int& col)
+{
+  const unsigned p0 = c * kChunk;  // wave-uniform
+  const unsigned r0 = p0 / w;
+  unsigned cc = p0 - r0 * w + (unsigned)lane;
+  unsigned rr = r0;
+  if (w >= (unsigned)kChunk) {
+    if (cc >= w) {
+      cc -= w;
+      ++rr;
+    }
+  } else {
+    rr += cc / w;
+    cc = cc % w;
+  }
+  row = (int)rr;
+  col = (int)cc;
+}
+
+// A1..A3 for the pixel at (row, col), pose in registers
+__device__ __forceinline__ bool depth_point_rc(const DepthSrc& s, const float* aff, int frame, unsigned pix, int row,
+                                               int col, float& ox, float& oy, float& oz)
+{
+  const uint16_t d = s.depth[(size_t)frame * s.ppf + pix];
+  const float z = (float)d / s.scale;
+  if (!(z < s.max_d && z > s.min_d)) return false;
+  const float x = ((float)col - s.cx) * z / s.fx;
+  const float y = ((float)row - s.cy) * z / s.fy;
+  apply_affine(aff, x, y, z, ox, oy, oz);
+  return true;
+}
+
+// Pass 1: bbox + survivor count per frame (getMinMax3D) and the number of groups per chunk.
+// Groups are found on the un-shifted cell triple floor(p * inv_leaf), which needs no bbox.
+__global__ void __launch_bounds__(kBlock)
+k_bbox_groups(DepthSrc src, FrameInfo* fi, float inv_xy, float inv_z, unsigned cpf, uint32_t* grp_cnt)
+{
+  const int frame = blockIdx.y;
+  const int lane = threadIdx.x & (kWave - 1);
+  const unsigned wv = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+  const unsigned nwv = gridDim.x * (kBlock / kWave);
+  float aff[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) aff[k] = fi[frame].aff[k];
+  float mn[3] = {INFINITY, INFINITY, INFINITY};
+  float mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  int cnt = 0;
+  for (unsigned c = wv; c < cpf; c += nwv) {
+    const unsigned pix = c * kChunk + lane;
+    int row, col;
+    chunk_rowcol(c, lane, (unsigned)src.w, row, col);
+    float x = 0.f, y = 0.f, z = 0.f;
+    const bool ok = pix < src.ppf && depth_point_rc(src, aff, frame, pix, row, col, x, y, z);
+    const float gx = floorf(x * inv_xy), gy = floorf(y * inv_xy), gz = floorf(z * inv_z);
+    if (ok) {
+      mn[0] = fminf(mn[0], x);
+      mn[1] = fminf(mn[1], y);
+      mn[2] = fminf(mn[2], z);
+      mx[0] = fmaxf(mx[0], x);
+      mx[1] = fmaxf(mx[1], y);
+      mx[2] = fmaxf(mx[2], z);
+      ++cnt;
+    }
+    unsigned long long mg;
+    const unsigned ng = chunk_groups<false>(ok, gx, gy, gz, mg);
+    if (lane == 0) grp_cnt[(size_t)frame * cpf + c] = ng;
+  }
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      mn[d] = fminf(mn[d], __shfl_down(mn[d], off));
+      mx[d] = fmaxf(mx[d], __shfl_down(mx[d], off));
+    }
+    cnt += __shfl_down(cnt, off);
+  }
+  // one set of atomics per block (hundreds of same-address atomics per frame serialise in L2)
+  __shared__ float s_mn[kBlock / kWave][3], s_mx[kBlock / kWave][3];
+  __shared__ int s_cnt[kBlock / kWave];
+  const int w_in_b = threadIdx.x / kWave;
+  if (lane == 0) {
+    for (int d = 0; d < 3; ++d) {
+      s_mn[w_in_b][d] = mn[d];
+      s_mx[w_in_b][d] = mx[d];
+    }
+    s_cnt[w_in_b] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kBlock / kWave; ++w) {
+      for (int d = 0; d < 3; ++d) {
+        mn[d] = fminf(mn[d], s_mn[w][d]);
+        mx[d] = fmaxf(mx[d], s_mx[w][d]);
+      }
+      cnt += s_cnt[w];
+    }
+    if (cnt > 0) {
+      for (int d = 0; d < 3; ++d) {
+        atomicMin(&fi[frame].bb_min[d], f2ord(mn[d]));
+        atomicMax(&fi[frame].bb_max[d], f2ord(mx[d]));
+      }
+      atomicAdd(&fi[frame].n_raw, cnt);
+    }
+  }
+}
+
+// Pass 2: one record per group: sort key = frame << cell_bits | PCL voxel index, payload =
+// (global chunk id, 64-bit pixel mask).  grp_off = exclusive scan of pass 1's counts.
+template <class KeyT>
+__global__ void __launch_bounds__(kBlock)
+k_group_records(DepthSrc src, const FrameInfo* fi, float inv_xy, float inv_z, int cell_bits, unsigned cpf,
+                const uint32_t* grp_off, KeyT* rkey, uint32_t* rval, uint4* rec)
+{
+  const int frame = blockIdx.y;
+  const int lane = threadIdx.x & (kWave - 1);
+  const unsigned wv = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+  const unsigned nwv = gridDim.x * (kBlock / kWave);
+  const FrameInfo& F = fi[frame];
+  float aff[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) aff[k] = F.aff[k];
+  const float mb0 = (float)F.min_b[0], mb1 = (float)F.min_b[1], mb2 = (float)F.min_b[2];
+  const int d0 = F.div_b[0], d01 = F.div_b[0] * F.div_b[1];
+  const KeyT fbits = (KeyT)frame << cell_bits;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (unsigned c = wv; c < cpf; c += nwv) {
+    const unsigned pix = c * kChunk + lane;
+    int row, col;
+    chunk_rowcol(c, lane, (unsigned)src.w, row, col);
+    float x = 0.f, y = 0.f, z = 0.f;
+    const bool ok = pix < src.ppf && depth_point_rc(src, aff, frame, pix, row, col, x, y, z);
+    const float gx = floorf(x * inv_xy), gy = floorf(y * inv_xy), gz = floorf(z * inv_z);
+    unsigned long long my_grp;
+    chunk_groups<true>(ok, gx, gy, gz, my_grp);
+    const unsigned long long leaders = __ballot(my_grp != 0ull);
+    if (my_grp) {
+      const size_t cg = (size_t)frame * cpf + c;
+      const unsigned o = grp_off[cg] + (unsigned)__popcll(leaders & lt);
+      const int i0 = (int)(gx - mb0), i1 = (int)(gy - mb1), i2 = (int)(gz - mb2);
+      rkey[o] = fbits | (KeyT)(unsigned)(i0 + i1 * d0 + i2 * d01);
+      rval[o] = o;
+      rec[o] = make_uint4((unsigned)cg, (unsigned)my_grp, (unsigned)(my_grp >> 32), 0u);
+    }
+  }
+}
+
+// Centroids from the sorted group records: one lane per voxel, records in sorted (= chunk)
+// order, mask bits from 0 upwards.
+template <class KeyT>
+__global__ void __launch_bounds__(kBlock)
+k_centroids_groups(DepthSrc src, const FrameInfo* fi, const KeyT* unique, const uint32_t* run_start,
+                   const uint32_t* run_count, const uint32_t* sval, const uint4* rec, unsigned n_vox, int cell_bits,
+                   unsigned cpf, float4* vox, int* vox_frame)
+{
+  const unsigned v = blockIdx.x * kBlock + threadIdx.x;
+  if (v >= n_vox) return;
+  const int frame = (int)(unique[v] >> cell_bits);
+  float aff[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) aff[k] = fi[frame].aff[k];
+  const unsigned start = run_start[v], cnt = run_count[v];
+  const unsigned chunk0 = (unsigned)frame * cpf;
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  unsigned n = 0;
+  for (unsigned e = 0; e < cnt; ++e) {
+    const uint4 r = rec[sval[start + e]];
+    const unsigned base = (r.x - chunk0) * kChunk;
+    unsigned long long m = (unsigned long long)r.y | ((unsigned long long)r.z << 32);
+    n += (unsigned)__popcll(m);
+    while (m) {
+      const int b = __ffsll((long long)m) - 1;
+      m &= m - 1ull;
+      float x = 0.f, y = 0.f, z = 0.f;
+      depth_point(src, aff, frame, base + (unsigned)b, x, y, z);
+      sx += x;
+      sy += y;
+      sz += z;
+    }
+  }
+  const float c = (float)n;
+  vox[v] = make_float4(sx / c, sy / c, sz / c, 0.f);
+  vox_frame[v] = frame;
 }
 
 // first voxel of each frame = lower_bound over the unique keys

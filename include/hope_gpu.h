@@ -177,6 +177,9 @@ HOPE_API int hope_profile_enable(hope_ctx* ctx, int on);
 HOPE_API int hope_profile_stage_count(void);
 HOPE_API int hope_profile_stage(hope_ctx* ctx, int stage, const char** name, double* total_ms,
                                 int64_t* launches);
+/* ALGORITHMIC bytes (the bytes the stage must read and write once, from
+ * the sizes of the calls made while enabled) moved by the same timed regions */
+HOPE_API int hope_profile_stage_bytes(hope_ctx* ctx, int stage, double* alg_bytes);
 
 #ifdef __cplusplus
 }

@@ -179,6 +179,35 @@ def test_neighbour_list_overflow_branch(hip_lib, oracle_lib, monkeypatch):
     assert_frame_equal(o, g, 0)
 
 
+def test_depth_frames_through_the_per_pixel_sort(hip_lib, oracle_lib, monkeypatch):
+    """Depth frames normally take the (chunk, voxel)-group voxel stage; the knob sends them through
+    the per-pixel sort that point clouds use, which must give the same bits."""
+    depth, t, q = synth_frames(3, first=21)
+    monkeypatch.setenv("HOPE_DEBUG_PIXEL_SORT", "1")
+    g = HopeContext(hip_lib)
+    monkeypatch.delenv("HOPE_DEBUG_PIXEL_SORT")
+    g2, o = HopeContext(hip_lib), HopeContext(oracle_lib)
+    for c in (g, g2, o):
+        c.set_frame_poses(t, q)
+        assert c.segment_depth(depth) == 0
+    for f in range(3):
+        assert_frame_equal(o, g, f)
+        assert_frame_equal(o, g2, f)
+
+
+def test_odd_image_shapes(hip_lib, oracle_lib):
+    """Widths that are not a multiple of the 64-pixel chunk, a ragged last chunk, tiny images."""
+    depth, t, q = synth_frames(2, first=40)
+    for (h, w) in ((37, 100), (480, 333), (1, 64), (3, 5), (65, 63)):
+        d = np.ascontiguousarray(depth[:, 100:100 + h, 200:200 + w])
+        g, o = both(hip_lib, oracle_lib)
+        for c in (g, o):
+            c.set_frame_poses(t, q)
+            c.segment_depth(d)
+        for f in range(2):
+            assert_frame_equal(o, g, f, check_transformed=(h == 37))
+
+
 def test_invalid_arguments(hip_lib):
     import ctypes as C
     g = HopeContext(hip_lib)
