@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "neighbours.hpp"
 #include "prims.hpp"
 
 using namespace hope;
@@ -127,6 +128,7 @@ struct hope_ctx {
   std::string err;
   double whole_ms = 0, ref_ms = 0;
   int normals_cap_small = 0;  // test knob: force the neighbour-list overflow path
+  int ablate = 0;             // timing experiments only (HOPE_DEBUG_ABLATE): wrong results
   int pixel_sort = 0;         // test knob: depth frames through the per-pixel sort (the cloud path's voxel stage)
   uint32_t* d_grp_cnt = nullptr;  // depth path: groups per chunk, then its exclusive scan
   uint32_t* d_grp_off = nullptr;
@@ -520,16 +522,14 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   ALLOC(d_normals, float4, n_vox);
   c->d_normals = d_normals;
   pm = prof_mark(c);
+  const dim3 tile_grid(std::max(1u, c->h_glob->max_tiles), F);
   if (c->normals_cap_small) {
-    hipLaunchKernelGGL((k_normals<CK, 4>), dim3(nblk(n_vox)), dim3(kBlock), 0, s, spt, ck_out, col_first,
-                       d_vox_frame, c->d_fi, n_vox, c->inv_xy, c->inv_z, zbits, c->radius, c->r2, c->ring,
-                       d_normals);
+    hipLaunchKernelGGL((k_normals_tile<2>), tile_grid, dim3(kBlock), 0, s, spt, col_first, c->d_fi, c->inv_xy,
+                       c->r2, c->ring, d_normals, c->ablate);
   } else {
-    hipLaunchKernelGGL((k_normals<CK, 64>), dim3(nblk(n_vox)), dim3(kBlock), 0, s, spt, ck_out, col_first,
-                       d_vox_frame, c->d_fi, n_vox, c->inv_xy, c->inv_z, zbits, c->radius, c->r2, c->ring,
-                       d_normals);
+    hipLaunchKernelGGL((k_normals_tile<16>), tile_grid, dim3(kBlock), 0, s, spt, col_first, c->d_fi, c->inv_xy,
+                       c->r2, c->ring, d_normals, c->ablate);
   }
-
   prof_close(c, ST_NORMALS, pm, (16.0 + 16.0) * n_vox);
   // ---- A7 gate + compaction ---------------------------------------------------------
   uint32_t *flags, *fscan;
@@ -570,13 +570,12 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   c->d_knn = knn;
   pm = prof_mark(c);
   if (K <= 8) {
-    hipLaunchKernelGGL((k_knn<CK, 8>), dim3(nblk(n_vox)), dim3(kBlock), 0, s, spt, ck_out, col_first, d_vox_frame,
-                       fit_rank, c->d_fi, n_vox, c->inv_xy, c->inv_z, c->cfg.th_xy, zbits, K, knn);
+    hipLaunchKernelGGL((k_knn_tile<8>), tile_grid, dim3(kBlock), 0, s, spt, col_first, fit_rank, c->d_fi, c->inv_xy,
+                       c->cfg.th_xy, K, knn);
   } else {
-    hipLaunchKernelGGL((k_knn<CK, kMaxKnn>), dim3(nblk(n_vox)), dim3(kBlock), 0, s, spt, ck_out, col_first,
-                       d_vox_frame, fit_rank, c->d_fi, n_vox, c->inv_xy, c->inv_z, c->cfg.th_xy, zbits, K, knn);
+    hipLaunchKernelGGL((k_knn_tile<kMaxKnn>), tile_grid, dim3(kBlock), 0, s, spt, col_first, fit_rank, c->d_fi,
+                       c->inv_xy, c->cfg.th_xy, K, knn);
   }
-
   prof_close(c, ST_KNN, pm, 16.0 * n_vox + 4.0 * K * (double)n_fit);
   // ---- A9 region growing as min-rank reachability -----------------------------------
   int *rank, *seed_node, *parent, *L, *root, *label;
@@ -829,6 +828,8 @@ HOPE_API int hope_create(const hope_config* cfg, hope_ctx** out)
   }
   const char* knob = std::getenv("HOPE_DEBUG_SMALL_NB_CAP");
   c->normals_cap_small = (knob && knob[0] == '1') ? 1 : 0;
+  knob = std::getenv("HOPE_DEBUG_ABLATE");
+  c->ablate = knob ? std::atoi(knob) : 0;
   knob = std::getenv("HOPE_DEBUG_PIXEL_SORT");
   c->pixel_sort = (knob && knob[0] == '1') ? 1 : 0;
   *out = c;

@@ -48,6 +48,7 @@ struct Globals {  // scalars produced on device, read back at the sync points
   unsigned int n_vox_total;
   unsigned int pad;
   unsigned int n_groups;  // depth path: number of (chunk, voxel) group records
+  unsigned int max_tiles; // largest per-frame count of 16x16-column tiles (neighbours.hpp)
 };
 
 struct DepthSrc {
@@ -193,13 +194,14 @@ __global__ void __launch_bounds__(1024) k_frame_grid(FrameInfo* fi, int n_frames
   // scan of the per-frame column-table sizes
   __shared__ unsigned s_scan[1024];
   __shared__ unsigned long long s_max_cells;
-  __shared__ unsigned s_max_dz, s_any_over, s_carry;
+  __shared__ unsigned s_max_dz, s_any_over, s_carry, s_max_tiles;
   const int tid = threadIdx.x;
   if (tid == 0) {
     s_max_cells = 1;
     s_max_dz = 1;
     s_any_over = 0;
     s_carry = 0;
+    s_max_tiles = 0;
   }
   __syncthreads();
   for (int base = 0; base < n_frames; base += 1024) {
@@ -235,6 +237,7 @@ __global__ void __launch_bounds__(1024) k_frame_grid(FrameInfo* fi, int n_frames
           atomicMax(&s_max_cells, (unsigned long long)cells);
           atomicMax(&s_max_dz, (unsigned)div_b[2]);
           ncols = (unsigned)(div_b[0] * div_b[1]) + 1u;
+          atomicMax(&s_max_tiles, (unsigned)(((div_b[0] + 15) / 16) * ((div_b[1] + 15) / 16)));
         }
       }
       for (int d = 0; d < 3; ++d) {
@@ -265,6 +268,7 @@ __global__ void __launch_bounds__(1024) k_frame_grid(FrameInfo* fi, int n_frames
     g->total_cols = s_carry;
     g->max_div_z = s_max_dz;
     g->any_overflow = s_any_over;
+    g->max_tiles = s_max_tiles;
   }
 }
 
@@ -423,10 +427,11 @@ __device__ __forceinline__ float readlane_f(float v, int lane)
 // use); the 4-wait-state rule for a VALU-written lane select does not apply to an SALU write.
 __device__ __forceinline__ void writelane_u64(unsigned long long uniform_val, int uniform_lane, int& lo, int& hi)
 {
-  asm("s_mov_b32 m0, %4\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
-      : "+v"(lo), "+v"(hi)
-      : "s"((int)(unsigned)uniform_val), "s"((int)(unsigned)(uniform_val >> 32)), "s"(uniform_lane)
-      : "m0");
+  int saved_m0;  // M0 is reserved by the compiler: saved and restored inside the statement
+  asm("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tv_writelane_b32 %0, %3, m0\n\t"
+      "v_writelane_b32 %1, %4, m0\n\ts_mov_b32 m0, %2"
+      : "+v"(lo), "+v"(hi), "=&s"(saved_m0)
+      : "s"((int)(unsigned)uniform_val), "s"((int)(unsigned)(uniform_val >> 32)), "s"(uniform_lane));
 }
 
 // A1..A3 with the pose held in registers (same arithmetic as load_point(DepthSrc))
@@ -976,158 +981,6 @@ __device__ inline void eigen33_smallest(const float* mat, float& eigenvalue, flo
   evec[2] = vz / s;
 }
 
-// ---- K6: normals (pcl::NormalEstimation radius search + computePointNormal) ------------
-// utilities.cpp:428-446; neighbours within dist2 < r2, accumulated in (dist2, index)
-// order.  One thread per down-sampled point, walking the 5x5 column stencil.
-struct Nb {
-  float d2;
-  unsigned idx;   // PCL-order index (tie-break)
-  unsigned spos;  // position in the sorted copy
-};
-
-template <class KeyT, int CAP>
-__global__ void __launch_bounds__(kBlock)
-k_normals(const float4* spt, const KeyT* skeys, const uint32_t* col_first, const int* vox_frame,
-          const FrameInfo* fi, unsigned n_vox, float inv_xy, float inv_z, int zbits, float radius, float r2,
-          int ring, float4* normals)
-{
-  const unsigned s = blockIdx.x * kBlock + threadIdx.x;
-  if (s >= n_vox) return;
-  const float4 q = spt[s];
-  const unsigned qv = __float_as_uint(q.w);
-  const FrameInfo& F = fi[vox_frame[qv]];
-  const int cqx = clampi(cell_unclamped(q.x, inv_xy, F.min_b[0]), 0, F.div_b[0] - 1);
-  const int cqy = clampi(cell_unclamped(q.y, inv_xy, F.min_b[1]), 0, F.div_b[1] - 1);
-  const int czlo = clampi(cell_unclamped(q.z - radius, inv_z, F.min_b[2]) - 1, 0, F.div_b[2] - 1);
-  const int czhi = clampi(cell_unclamped(q.z + radius, inv_z, F.min_b[2]) + 1, 0, F.div_b[2] - 1);
-  const int x0 = max(cqx - ring, 0), x1 = min(cqx + ring, F.div_b[0] - 1);
-  const int y0 = max(cqy - ring, 0), y1 = min(cqy + ring, F.div_b[1] - 1);
-
-  Nb nb[CAP];
-  int total = 0;
-  for (int cy = y0; cy <= y1; ++cy) {
-    for (int cx = x0; cx <= x1; ++cx) {
-      const unsigned col = (unsigned)F.col_off + (unsigned)(cy * F.div_b[0] + cx);
-      unsigned lo = col_first[col];
-      const unsigned end = col_first[col + 1];
-      const KeyT klo = ((KeyT)col << zbits) | (KeyT)(unsigned)czlo;
-      const KeyT khi = ((KeyT)col << zbits) | (KeyT)(unsigned)czhi;
-      unsigned hi = end;
-      while (lo < hi) {  // first entry with key >= klo
-        const unsigned mid = (lo + hi) >> 1;
-        if (skeys[mid] < klo) lo = mid + 1; else hi = mid;
-      }
-      for (unsigned e = lo; e < end && skeys[e] <= khi; ++e) {
-        const float4 p = spt[e];
-        const float d = dist2(q.x, q.y, q.z, p.x, p.y, p.z);
-        if (d < r2) {
-          if (total < CAP) {
-            nb[total].d2 = d;
-            nb[total].idx = __float_as_uint(p.w);
-            nb[total].spos = e;
-          }
-          ++total;
-        }
-      }
-    }
-  }
-  float4 out = make_float4(NAN, NAN, NAN, NAN);
-  if (total >= 3) {
-    float accu[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (total <= CAP) {
-      // insertion sort by (d2, idx), then the single-pass accumulation of
-      // computeMeanAndCovarianceMatrix (PCL 1.8.1 centroid.hpp, float, dense branch)
-      for (int i = 1; i < total; ++i) {
-        const Nb t = nb[i];
-        int j = i - 1;
-        while (j >= 0 && di_less(t.d2, t.idx, nb[j].d2, nb[j].idx)) {
-          nb[j + 1] = nb[j];
-          --j;
-        }
-        nb[j + 1] = t;
-      }
-      for (int i = 0; i < total; ++i) {
-        const float4 p = spt[nb[i].spos];
-        accu[0] += p.x * p.x;
-        accu[1] += p.x * p.y;
-        accu[2] += p.x * p.z;
-        accu[3] += p.y * p.y;
-        accu[4] += p.y * p.z;
-        accu[5] += p.z * p.z;
-        accu[6] += p.x;
-        accu[7] += p.y;
-        accu[8] += p.z;
-      }
-    } else {
-      // more neighbours than the register list holds: selection by repeated scans
-      float last_d = -1.f;
-      unsigned last_i = 0;
-      for (int t = 0; t < total; ++t) {
-        float best_d = INFINITY;
-        unsigned best_i = 0xffffffffu, best_e = 0;
-        for (int cy = y0; cy <= y1; ++cy) {
-          for (int cx = x0; cx <= x1; ++cx) {
-            const unsigned col = (unsigned)F.col_off + (unsigned)(cy * F.div_b[0] + cx);
-            const unsigned end = col_first[col + 1];
-            const KeyT khi = ((KeyT)col << zbits) | (KeyT)(unsigned)czhi;
-            for (unsigned e = col_first[col]; e < end && skeys[e] <= khi; ++e) {
-              const float4 p = spt[e];
-              const float d = dist2(q.x, q.y, q.z, p.x, p.y, p.z);
-              const unsigned pi = __float_as_uint(p.w);
-              if (d < r2 && (t == 0 || di_less(last_d, last_i, d, pi)) && di_less(d, pi, best_d, best_i)) {
-                best_d = d;
-                best_i = pi;
-                best_e = e;
-              }
-            }
-          }
-        }
-        const float4 p = spt[best_e];
-        accu[0] += p.x * p.x;
-        accu[1] += p.x * p.y;
-        accu[2] += p.x * p.z;
-        accu[3] += p.y * p.y;
-        accu[4] += p.y * p.z;
-        accu[5] += p.z * p.z;
-        accu[6] += p.x;
-        accu[7] += p.y;
-        accu[8] += p.z;
-        last_d = best_d;
-        last_i = best_i;
-      }
-    }
-    const float cnt = (float)total;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) accu[k] /= cnt;
-    float cov[9];
-    cov[0] = accu[0] - accu[6] * accu[6];
-    cov[1] = accu[1] - accu[6] * accu[7];
-    cov[2] = accu[2] - accu[6] * accu[8];
-    cov[4] = accu[3] - accu[7] * accu[7];
-    cov[5] = accu[4] - accu[7] * accu[8];
-    cov[8] = accu[5] - accu[8] * accu[8];
-    cov[3] = cov[1];
-    cov[6] = cov[2];
-    cov[7] = cov[5];
-    float eval, evec[3];
-    eigen33_smallest(cov, eval, evec);
-    float nx = evec[0], ny = evec[1], nz = evec[2];
-    const float eig_sum = cov[0] + cov[4] + cov[8];
-    float curvature = 0.f;
-    if (eig_sum != 0.f) curvature = fabsf(eval / eig_sum);
-    // flipNormalTowardsViewpoint(point, 0, 0, 0, ...)   (PCL 1.8.1 normal_3d.h)
-    const float vpx = 0.f - q.x, vpy = 0.f - q.y, vpz = 0.f - q.z;
-    const float cos_theta = (vpx * nx + vpy * ny + vpz * nz);
-    if (cos_theta < 0.f) {
-      nx *= -1.f;
-      ny *= -1.f;
-      nz *= -1.f;
-    }
-    out = make_float4(nx, ny, nz, curvature);
-  }
-  normals[qv] = out;
-}
-
 // ---- K7: |nz| > th_norm gate (utilities.cpp:629-645) + order-preserving compaction -----
 __global__ void __launch_bounds__(kBlock)
 k_fit_flags(const float4* normals, unsigned n_vox, float th_norm, uint32_t* flags)
@@ -1164,101 +1017,6 @@ __global__ void k_frame_fit_ranges(FrameInfo* fi, int n_frames, const uint32_t* 
   const unsigned b = scan[fi[f].vox_start + fi[f].n_vox];
   fi[f].fit_start = (int)a;
   fi[f].n_fit = (int)(b - a);
-}
-
-// ---- K8: exact k nearest neighbours among the fit points (z_growing.cpp:196-226) -------
-// Ring expansion over the column index until the k-th distance is provably smaller than
-// the distance to any column not yet visited.
-template <class KeyT, int KMAX>
-__global__ void __launch_bounds__(kBlock)
-k_knn(const float4* spt, const KeyT* skeys, const uint32_t* col_first, const int* vox_frame, const int* fit_rank,
-      const FrameInfo* fi, unsigned n_vox, float inv_xy, float inv_z, float cell_xy, int zbits, int K,
-      int* knn_out)
-{
-  const unsigned s = blockIdx.x * kBlock + threadIdx.x;
-  if (s >= n_vox) return;
-  const float4 q = spt[s];
-  const unsigned qv = __float_as_uint(q.w);
-  const int g = fit_rank[qv];
-  if (g < 0) return;
-  const FrameInfo& F = fi[vox_frame[qv]];
-  const int k = min(K, F.n_fit);
-  const int cqx = clampi(cell_unclamped(q.x, inv_xy, F.min_b[0]), 0, F.div_b[0] - 1);
-  const int cqy = clampi(cell_unclamped(q.y, inv_xy, F.min_b[1]), 0, F.div_b[1] - 1);
-
-  float bd[KMAX];
-  unsigned bi[KMAX];
-#pragma unroll
-  for (int j = 0; j < KMAX; ++j) {
-    bd[j] = INFINITY;
-    bi[j] = 0xffffffffu;
-  }
-  const int max_ring = max(max(cqx, F.div_b[0] - 1 - cqx), max(cqy, F.div_b[1] - 1 - cqy));
-  for (int R = 0; R <= max_ring; ++R) {
-    const int y0 = cqy - R, y1 = cqy + R, x0 = cqx - R, x1 = cqx + R;
-    for (int cy = max(y0, 0); cy <= min(y1, F.div_b[1] - 1); ++cy) {
-      const bool edge_row = (cy == y0 || cy == y1);
-      const int step = edge_row ? 1 : max(2 * R, 1);
-      for (int cx = x0; cx <= x1; cx += step) {
-        if (cx < 0 || cx >= F.div_b[0]) continue;
-        const unsigned col = (unsigned)F.col_off + (unsigned)(cy * F.div_b[0] + cx);
-        unsigned e = col_first[col];
-        const unsigned end = col_first[col + 1];
-        KeyT khi = ((KeyT)col << zbits) | (((KeyT)1 << zbits) - 1);
-        float worst = INFINITY;
-#pragma unroll
-        for (int j = 0; j < KMAX; ++j)
-          if (j == k - 1) worst = bd[j];
-        if (worst < INFINITY && end - e > 4) {
-          // list is full: only z within sqrt(worst) can still enter
-          const float rz = __builtin_sqrtf(worst) * 1.000001f + 1e-12f;
-          const int czlo = clampi(cell_unclamped(q.z - rz, inv_z, F.min_b[2]) - 1, 0, F.div_b[2] - 1);
-          const int czhi = clampi(cell_unclamped(q.z + rz, inv_z, F.min_b[2]) + 1, 0, F.div_b[2] - 1);
-          const KeyT klo = ((KeyT)col << zbits) | (KeyT)(unsigned)czlo;
-          khi = ((KeyT)col << zbits) | (KeyT)(unsigned)czhi;
-          unsigned hi = end;
-          while (e < hi) {
-            const unsigned mid = (e + hi) >> 1;
-            if (skeys[mid] < klo) e = mid + 1; else hi = mid;
-          }
-        }
-        for (; e < end && skeys[e] <= khi; ++e) {
-          const float4 p = spt[e];
-          const unsigned pv = __float_as_uint(p.w);
-          if (fit_rank[pv] < 0) continue;
-          const float d = dist2(q.x, q.y, q.z, p.x, p.y, p.z);
-          // sorted insertion with compile-time register indices
-          bool inserted_here;
-#pragma unroll
-          for (int j = KMAX - 1; j >= 1; --j) {
-            if (j < k) {
-              const bool before_prev = di_less(d, pv, bd[j - 1], bi[j - 1]);
-              inserted_here = di_less(d, pv, bd[j], bi[j]);
-              const float nd = before_prev ? bd[j - 1] : (inserted_here ? d : bd[j]);
-              const unsigned ni = before_prev ? bi[j - 1] : (inserted_here ? pv : bi[j]);
-              bd[j] = nd;
-              bi[j] = ni;
-            }
-          }
-          if (di_less(d, pv, bd[0], bi[0])) {
-            bd[0] = d;
-            bi[0] = pv;
-          }
-        }
-      }
-    }
-    // every unvisited column is more than (R - slack) cells away in x or y
-    const float reach = ((float)R - F.slack) * cell_xy * 0.999999f;
-    float kth = INFINITY;
-#pragma unroll
-    for (int j = 0; j < KMAX; ++j)
-      if (j == k - 1) kth = bd[j];
-    if (reach > 0.f && kth < reach * reach * 0.999999f) break;
-  }
-#pragma unroll
-  for (int j = 0; j < KMAX; ++j) {
-    if (j < K) knn_out[(size_t)g * K + j] = (j < k && bi[j] != 0xffffffffu) ? fit_rank[bi[j]] : -1;
-  }
 }
 
 // ---- K9: ZGrowing as min-rank reachability (z_growing.cpp:229-364) ----------------------
