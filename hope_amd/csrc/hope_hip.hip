@@ -525,10 +525,10 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   const dim3 tile_grid(std::max(1u, c->h_glob->max_tiles), F);
   if (c->normals_cap_small) {
     hipLaunchKernelGGL((k_normals_tile<2>), tile_grid, dim3(kBlock), 0, s, spt, col_first, c->d_fi, c->inv_xy,
-                       c->r2, c->ring, d_normals, c->ablate);
+                       c->inv_z, c->radius, c->r2, c->ring, d_normals, c->ablate % 10);
   } else {
-    hipLaunchKernelGGL((k_normals_tile<16>), tile_grid, dim3(kBlock), 0, s, spt, col_first, c->d_fi, c->inv_xy,
-                       c->r2, c->ring, d_normals, c->ablate);
+    hipLaunchKernelGGL((k_normals_tile<kNbCap>), tile_grid, dim3(kBlock), 0, s, spt, col_first, c->d_fi, c->inv_xy,
+                       c->inv_z, c->radius, c->r2, c->ring, d_normals, c->ablate % 10);
   }
   prof_close(c, ST_NORMALS, pm, (16.0 + 16.0) * n_vox);
   // ---- A7 gate + compaction ---------------------------------------------------------
@@ -571,10 +571,10 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   pm = prof_mark(c);
   if (K <= 8) {
     hipLaunchKernelGGL((k_knn_tile<8>), tile_grid, dim3(kBlock), 0, s, spt, col_first, fit_rank, c->d_fi, c->inv_xy,
-                       c->cfg.th_xy, K, knn);
+                       c->inv_z, c->cfg.th_xy, K, knn, c->ablate / 10);
   } else {
     hipLaunchKernelGGL((k_knn_tile<kMaxKnn>), tile_grid, dim3(kBlock), 0, s, spt, col_first, fit_rank, c->d_fi,
-                       c->inv_xy, c->cfg.th_xy, K, knn);
+                       c->inv_xy, c->inv_z, c->cfg.th_xy, K, knn, c->ablate / 10);
   }
   prof_close(c, ST_KNN, pm, 16.0 * n_vox + 4.0 * K * (double)n_fit);
   // ---- A9 region growing as min-rank reachability -----------------------------------
