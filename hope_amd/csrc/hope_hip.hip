@@ -571,10 +571,10 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   pm = prof_mark(c);
   if (K <= 8) {
     hipLaunchKernelGGL((k_knn_tile<8>), tile_grid, dim3(kBlock), 0, s, spt, col_first, fit_rank, c->d_fi, c->inv_xy,
-                       c->inv_z, c->cfg.th_xy, K, knn, c->ablate / 10);
+                       c->inv_z, c->cfg.th_xy, K, knn, (c->ablate / 10) % 10);
   } else {
     hipLaunchKernelGGL((k_knn_tile<kMaxKnn>), tile_grid, dim3(kBlock), 0, s, spt, col_first, fit_rank, c->d_fi,
-                       c->inv_xy, c->inv_z, c->cfg.th_xy, K, knn, c->ablate / 10);
+                       c->inv_xy, c->inv_z, c->cfg.th_xy, K, knn, (c->ablate / 10) % 10);
   }
   prof_close(c, ST_KNN, pm, 16.0 * n_vox + 4.0 * K * (double)n_fit);
   // ---- A9 region growing as min-rank reachability -----------------------------------
@@ -589,16 +589,30 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   pm = prof_mark(c);
   hipLaunchKernelGGL(k_seed_ranks, dim3(gb), dim3(kBlock), 0, s, c->d_fi, fit_frame, n_fit, rank, seed_node, parent,
                      L);
-  hipLaunchKernelGGL(k_union_mutual, dim3(gb), dim3(kBlock), 0, s, knn, fit_pt, n_fit, K, c->cfg.th_z, parent);
+  uint32_t* cross;
+  uint2* edges;
+  ALLOC(cross, uint32_t, n_fit);
+  ALLOC(edges, uint2, (size_t)n_fit * K);
+  unsigned* d_n_edges = &c->d_glob->n_runs;  // free again after the voxel stage
+  hipLaunchKernelGGL(k_union_local, dim3(nblk(n_fit, kUfTile)), dim3(kBlock), 0, s, knn, fit_pt, n_fit, K,
+                     c->cfg.th_z, parent, cross);
+  hipLaunchKernelGGL(k_union_cross, dim3(gb), dim3(kBlock), 0, s, knn, cross, n_fit, K, parent);
   hipLaunchKernelGGL(k_flatten_roots, dim3(gb), dim3(kBlock), 0, s, parent, rank, n_fit, root, L);
-  prof_close(c, ST_LABELS, pm, (4.0 * K + 16.0 + 5 * 4.0) * n_fit);
+  HIPCHK(hipMemsetAsync(d_n_edges, 0, sizeof(unsigned), s));
+  hipLaunchKernelGGL(k_cross_edges, dim3(gb), dim3(kBlock), 0, s, knn, fit_pt, root, n_fit, K, c->cfg.th_z, edges,
+                     d_n_edges);
+  prof_close(c, ST_LABELS, pm, (2.0 * 4.0 * K + 2.0 * 16.0 + 6 * 4.0) * n_fit);
+  const unsigned ge = std::min(gb, 2048u);
   for (int iter = 0; iter < 100000; ++iter) {
     pm = prof_mark(c);
     HIPCHK(hipMemsetAsync(&c->d_glob->changed, 0, sizeof(unsigned), s));
-    for (int rep = 0; rep < 2; ++rep)
-      hipLaunchKernelGGL(k_label_sweep, dim3(gb), dim3(kBlock), 0, s, knn, fit_pt, root, seed_node, n_fit, K,
-                         c->cfg.th_z, L, &c->d_glob->changed);
-    prof_close(c, ST_LABELS, pm, 2.0 * (4.0 * K + 16.0 + 4.0 + 4.0) * n_fit);
+    for (int rep = 0; rep < 2; ++rep) {
+      hipLaunchKernelGGL(k_label_shortcut, dim3(gb), dim3(kBlock), 0, s, root, seed_node, n_fit, L,
+                         &c->d_glob->changed);
+      hipLaunchKernelGGL(k_label_sweep_edges, dim3(ge), dim3(kBlock), 0, s, edges, d_n_edges, L,
+                         &c->d_glob->changed);
+    }
+    prof_close(c, ST_LABELS, pm, 2.0 * 4.0 * n_fit);
     int st = sync_globals(c);
     if (st != HOPE_OK) return st;
     if (!c->h_glob->changed) break;

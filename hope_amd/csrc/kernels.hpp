@@ -1085,20 +1085,88 @@ __device__ __forceinline__ bool z_edge(const float4* fit_pt, int a, int b, float
   return fabsf(fit_pt[a].z - fit_pt[b].z) < th_z;  // validatePoint, smooth mode
 }
 
+// Union over the mutual valid edges, two levels.  Fit points are numbered in VoxelGrid order
+// (z layer, then y, then x), so the points of a horizontal surface sit in a few long index runs
+// and most of their edges join two points of the same 1024-point block: those are united in an
+// LDS union-find (no global atomics, no long pointer chases through HBM); what leaves the block
+// is noted as a bit mask per point and united in global memory by k_union_cross.
+constexpr int kUfPer = 4;
+constexpr int kUfTile = kBlock * kUfPer;
+
+__device__ __forceinline__ int uf_find_lds(int* parent, int x)
+{
+  int p = parent[x];
+  while (p != x) {
+    const int gp = parent[p];
+    if (gp != p) parent[x] = gp;
+    x = p;
+    p = gp;
+  }
+  return x;
+}
+
 __global__ void __launch_bounds__(kBlock)
-k_union_mutual(const int* knn, const float4* fit_pt, unsigned n_fit, int K, float th_z, int* parent)
+k_union_local(const int* knn, const float4* fit_pt, unsigned n_fit, int K, float th_z, int* parent, uint32_t* cross)
+{
+  __shared__ int s_par[kUfTile];
+  const unsigned base = blockIdx.x * kUfTile;
+#pragma unroll
+  for (int i = 0; i < kUfPer; ++i) s_par[threadIdx.x + i * kBlock] = threadIdx.x + i * kBlock;
+  __syncthreads();
+  for (int i = 0; i < kUfPer; ++i) {
+    const int l = threadIdx.x + i * kBlock;
+    const unsigned g = base + l;
+    if (g >= n_fit) break;
+    const float zg = fit_pt[g].z;
+    uint32_t crossmask = 0u;
+    for (int j = 0; j < K; ++j) {
+      const int v = knn[(size_t)g * K + j];
+      if (v < 0) break;
+      if (v <= (int)g) continue;  // each mutual pair once, from the smaller index
+      if (!(fabsf(zg - fit_pt[v].z) < th_z)) continue;  // validatePoint, smooth mode
+      bool mutual = false;
+      for (int t = 0; t < K; ++t) mutual |= (knn[(size_t)v * K + t] == (int)g);
+      if (!mutual) continue;
+      if ((unsigned)v >= base + kUfTile) {
+        crossmask |= 1u << j;
+        continue;
+      }
+      int a = l, b = v - (int)base;
+      while (true) {
+        a = uf_find_lds(s_par, a);
+        b = uf_find_lds(s_par, b);
+        if (a == b) break;
+        if (a > b) {
+          const int t = a;
+          a = b;
+          b = t;
+        }
+        if (atomicCAS(&s_par[b], b, a) == b) break;  // hook the larger root under the smaller one
+      }
+    }
+    cross[g] = crossmask;
+  }
+  __syncthreads();
+  for (int i = 0; i < kUfPer; ++i) {
+    const int l = threadIdx.x + i * kBlock;
+    const unsigned g = base + l;
+    if (g >= n_fit) break;
+    int r = l;
+    while (s_par[r] != r) r = s_par[r];
+    parent[g] = (int)base + r;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_union_cross(const int* knn, const uint32_t* cross, unsigned n_fit, int K, int* parent)
 {
   const unsigned g = blockIdx.x * kBlock + threadIdx.x;
   if (g >= n_fit) return;
-  for (int j = 0; j < K; ++j) {
-    const int v = knn[(size_t)g * K + j];
-    if (v < 0) break;
-    if (v <= (int)g) continue;  // handle each mutual pair once (from the smaller index)
-    if (!z_edge(fit_pt, (int)g, v, th_z)) continue;
-    bool mutual = false;
-    for (int t = 0; t < K; ++t) mutual |= (knn[(size_t)v * K + t] == (int)g);
-    if (!mutual) continue;
-    int a = (int)g, b = v;
+  uint32_t m = cross[g];
+  while (m) {
+    const int j = __ffs((int)m) - 1;
+    m &= m - 1u;
+    int a = (int)g, b = knn[(size_t)g * K + j];
     while (true) {
       a = uf_find(parent, a);
       b = uf_find(parent, b);
@@ -1108,7 +1176,6 @@ k_union_mutual(const int* knn, const float4* fit_pt, unsigned n_fit, int K, floa
         a = b;
         b = t;
       }
-      // hook the larger root under the smaller one
       if (atomicCAS(&parent[b], b, a) == b) break;
     }
   }
@@ -1159,38 +1226,67 @@ k_flatten_roots(int* parent, const int* rank, unsigned n_fit, int* root, int* L)
   wave_atomic_min_by_key(L, r, rk, active);
 }
 
+// The valid directed edges that join two DIFFERENT mutual components are the only ones the label
+// sweeps need; on real scenes they are a few percent of all edges (region fringes).  Collected
+// once (order is irrelevant: atomicMin is commutative), then swept until nothing changes.
 __global__ void __launch_bounds__(kBlock)
-k_label_sweep(const int* knn, const float4* fit_pt, const int* root, const int* seed_node, unsigned n_fit, int K,
-              float th_z, int* L, unsigned* changed)
+k_cross_edges(const int* knn, const float4* fit_pt, const int* root, unsigned n_fit, int K, float th_z, uint2* edges,
+              unsigned* n_edges)
 {
   const unsigned g = blockIdx.x * kBlock + threadIdx.x;
-  if (g >= n_fit) return;
-  const int r = root[g];
-  int a = L[r];
-  bool ch = false;
-  if ((int)g == r) {
-    // shortcut: the seed that labels this component may itself carry a smaller label
-    const int w = seed_node[a];
-    const int aw = L[root[w]];
-    if (aw < a) {
-      atomicMin(&L[r], aw);
-      a = aw;
-      ch = true;
+  const bool live = g < n_fit;
+  const int r = live ? root[g] : 0;
+  const float zg = live ? fit_pt[g].z : 0.f;
+  const int lane = threadIdx.x & (kWave - 1);
+  for (int j = 0; j < K; ++j) {
+    bool emit = false;
+    int rv = 0;
+    if (live) {
+      const int v = knn[(size_t)g * K + j];
+      if (v >= 0 && v != (int)g) {
+        rv = root[v];
+        emit = rv != r && fabsf(zg - fit_pt[v].z) < th_z;
+      }
+    }
+    const unsigned long long em = __ballot(emit);
+    if (em) {
+      unsigned o = 0;
+      if (lane == __ffsll((long long)em) - 1) o = atomicAdd(n_edges, (unsigned)__popcll(em));
+      o = (unsigned)__shfl((int)o, __ffsll((long long)em) - 1);
+      if (emit) edges[o + (unsigned)__popcll(em & ((1ull << lane) - 1ull))] = make_uint2((unsigned)r, (unsigned)rv);
     }
   }
-  for (int j = 0; j < K; ++j) {
-    const int v = knn[(size_t)g * K + j];
-    if (v < 0) break;
-    if (v == (int)g) continue;
-    const int rv = root[v];
-    if (rv == r) continue;
-    if (!z_edge(fit_pt, (int)g, v, th_z)) continue;
-    if (a < L[rv]) {
-      const int old = atomicMin(&L[rv], a);
+}
+
+// one sweep over the component-level edges (source root, target root)
+__global__ void __launch_bounds__(kBlock)
+k_label_sweep_edges(const uint2* edges, const unsigned* n_edges, int* L, unsigned* changed)
+{
+  const unsigned n = *n_edges;
+  bool ch = false;
+  for (unsigned e = blockIdx.x * kBlock + threadIdx.x; e < n; e += gridDim.x * kBlock) {
+    const uint2 ed = edges[e];
+    const int a = L[ed.x];
+    if (a < L[ed.y]) {
+      const int old = atomicMin(&L[ed.y], a);
       ch |= (a < old);
     }
   }
   if (ch) *changed = 1u;
+}
+
+// shortcut: the seed that labels a component may itself carry a smaller label
+__global__ void __launch_bounds__(kBlock)
+k_label_shortcut(const int* root, const int* seed_node, unsigned n_fit, int* L, unsigned* changed)
+{
+  const unsigned g = blockIdx.x * kBlock + threadIdx.x;
+  if (g >= n_fit || root[g] != (int)g) return;
+  const int a = L[g];
+  const int aw = L[root[seed_node[a]]];
+  if (aw < a) {
+    atomicMin(&L[g], aw);
+    *changed = 1u;
+  }
 }
 
 // per rank value: number of points whose segment was seeded at that rank
