@@ -665,7 +665,7 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
     prof_close(c, ST_SEGMENTS, pm, (4.0 + 4.0 + 2 * 8.0 + 2 * 8.0) * n_fit);
     pm = prof_mark(c);
     // ---- A10..A12 -------------------------------------------------------------------
-    hipLaunchKernelGGL(k_cluster_verify_w, dim3(n_cl), dim3(kWave), 0, s, members, cl_first, fit_pt, fit_nrm, n_cl,
+    hipLaunchKernelGGL(k_cluster_verify_b, dim3(n_cl), dim3(kBlock), 0, s, members, cl_first, fit_pt, fit_nrm, n_cl,
                        c->th_angle, rec);
     prof_close(c, ST_VERIFY, pm, (4.0 + 16.0 + 16.0) * n_fit + 32.0 * n_cl);
     c->h_rec.resize(n_cl);

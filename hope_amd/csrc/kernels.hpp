@@ -1478,71 +1478,124 @@ k_cluster_verify(const uint32_t* members, const uint32_t* cl_first, const float4
   rec[c].pass = pass;
 }
 
-// ---- K10 (wave per cluster) --------------------------------------------------------------
-// Same sequential sums as k_cluster_verify, organised for the hardware: the 64 lanes fetch the
-// members' points / normals with coalesced index loads, form the per-point terms in parallel and
-// park them in LDS; then one lane per accumulator runs its chain over the tile in member order.
-constexpr int kVTile = 256;
+// ---- K10 (block per cluster) --------------------------------------------------------------
+// Same sequential sums as k_cluster_verify, organised for the hardware.  The reference's sums are
+// chains of dependent float adds in member order; a chain cannot be split, but the work around it
+// can: all 256 threads fetch the members' points / normals (coalesced index loads, 16-byte
+// gathers) and park the per-point terms in LDS, double-buffered, while the lanes of wave 0 that
+// own an accumulator run their chains over the previous tile with 16-byte LDS reads.  A chain
+// then costs about one dependent add (4 cycles) per member instead of a memory round trip.
+// Terms that the reference skips (a non-finite z, the other side of the split) enter as +0.0f,
+// which leaves a running sum that started at +0.0f bit-identical.
+constexpr int kVTile = 1024;
+constexpr int kVPer = kVTile / kBlock;
 
-__global__ void __launch_bounds__(kWave)
-k_cluster_verify_w(const uint32_t* members, const uint32_t* cl_first, const float4* fit_pt, const float4* fit_nrm,
+__device__ __forceinline__ float chain_sum(const float* sv, int n, float acc)
+{
+  int j = 0;
+  for (; j + 16 <= n; j += 16) {
+    const float4 a = *reinterpret_cast<const float4*>(sv + j);
+    const float4 b = *reinterpret_cast<const float4*>(sv + j + 4);
+    const float4 c = *reinterpret_cast<const float4*>(sv + j + 8);
+    const float4 d = *reinterpret_cast<const float4*>(sv + j + 12);
+    acc += a.x; acc += a.y; acc += a.z; acc += a.w;
+    acc += b.x; acc += b.y; acc += b.z; acc += b.w;
+    acc += c.x; acc += c.y; acc += c.z; acc += c.w;
+    acc += d.x; acc += d.y; acc += d.z; acc += d.w;
+  }
+  for (; j < n; ++j) acc += sv[j];
+  return acc;
+}
+
+__device__ __forceinline__ float block_reduce_minmax(float v, bool is_min, float* s_red)
+{
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    const float o = __shfl_xor(v, off);
+    v = is_min ? fminf(v, o) : fmaxf(v, o);
+  }
+  __syncthreads();
+  if ((threadIdx.x & (kWave - 1)) == 0) s_red[threadIdx.x / kWave] = v;
+  __syncthreads();
+  float r = s_red[0];
+  for (int w = 1; w < kBlock / kWave; ++w) r = is_min ? fminf(r, s_red[w]) : fmaxf(r, s_red[w]);
+  return r;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_cluster_verify_b(const uint32_t* members, const uint32_t* cl_first, const float4* fit_pt, const float4* fit_nrm,
                    unsigned n_cl, float th_angle, ClusterRec* rec)
 {
-  __shared__ float s_v[4][kVTile];
-  __shared__ unsigned char s_side[kVTile];
+  __shared__ __attribute__((aligned(16))) float s_v[2][6][kVTile];
+  __shared__ float s_bc[8];
+  __shared__ float s_red[kBlock / kWave];
+  __shared__ unsigned s_cnt[kBlock / kWave];
   const unsigned c = blockIdx.x;
   if (c >= n_cl) return;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const bool chain_wave = tid < kWave;
   const uint32_t* m = members + cl_first[c];
   const int sz = rec[c].size;
+  const int n_tiles = (sz + kVTile - 1) / kVTile;
 
-  // ---- pass 1: sum z (lane 0), sum nx, ny, |nz| (lanes 1..3); bbox in parallel ------------
+  // ---- pass 1: sum z (lane 0), sum nx, ny, |nz| (lanes 1..3); bbox + finite count in parallel ----
   float acc = 0.f;
   unsigned ct = 0;
   float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
-  for (int base = 0; base < sz; base += kVTile) {
-    const int tile = min(kVTile, sz - base);
-    for (int t = lane; t < tile; t += kWave) {
-      const unsigned g = m[base + t];
-      const float4 p = fit_pt[g];
-      const float4 nn = fit_nrm[g];
-      s_v[0][t] = p.z;
-      s_v[1][t] = nn.x;
-      s_v[2][t] = nn.y;
-      s_v[3][t] = fabsf(nn.z);
-      mnx = fminf(mnx, p.x);
-      mny = fminf(mny, p.y);
-      mxx = fmaxf(mxx, p.x);
-      mxy = fmaxf(mxy, p.y);
-    }
-    __syncthreads();
-    if (lane < 4) {
-      const float* sv = s_v[lane];
-      if (lane == 0) {
-        for (int j = 0; j < tile; ++j) {
-          const float v = sv[j];
-          if (isfinite(v)) {
-            acc += v;
-            ++ct;
-          }
-        }
-      } else {
-#pragma unroll 8
-        for (int j = 0; j < tile; ++j) acc += sv[j];
-      }
-    }
-    __syncthreads();
-  }
+  {
+    float4 rp[kVPer], rn[kVPer];
+    auto fetch = [&](int tile_i) {
 #pragma unroll
-  for (int off = kWave / 2; off > 0; off >>= 1) {
-    mnx = fminf(mnx, __shfl_xor(mnx, off));
-    mny = fminf(mny, __shfl_xor(mny, off));
-    mxx = fmaxf(mxx, __shfl_xor(mxx, off));
-    mxy = fmaxf(mxy, __shfl_xor(mxy, off));
+      for (int i = 0; i < kVPer; ++i) {
+        const int e = tile_i * kVTile + i * kBlock + tid;
+        if (e < sz) {
+          const unsigned g = m[e];
+          rp[i] = fit_pt[g];
+          rn[i] = fit_nrm[g];
+        }
+      }
+    };
+    fetch(0);
+    for (int ti = 0; ti < n_tiles; ++ti) {
+      const int buf = ti & 1;
+      const int tile = min(kVTile, sz - ti * kVTile);
+#pragma unroll
+      for (int i = 0; i < kVPer; ++i) {
+        const int t = i * kBlock + tid;
+        if (t < tile) {
+          const float4 p = rp[i];
+          const float4 nn = rn[i];
+          const bool fin = isfinite(p.z);
+          s_v[buf][0][t] = fin ? p.z : 0.f;
+          s_v[buf][1][t] = nn.x;
+          s_v[buf][2][t] = nn.y;
+          s_v[buf][3][t] = fabsf(nn.z);
+          ct += fin ? 1u : 0u;
+          mnx = fminf(mnx, p.x);
+          mny = fminf(mny, p.y);
+          mxx = fmaxf(mxx, p.x);
+          mxy = fmaxf(mxy, p.y);
+        }
+      }
+      __syncthreads();
+      if (ti + 1 < n_tiles) fetch(ti + 1);
+      if (chain_wave && lane < 4) acc = chain_sum(s_v[buf][lane], tile, acc);
+    }
   }
-  const float mid = __shfl(acc, 0);
-  const unsigned ctz = (unsigned)__shfl((int)ct, 0);
-  const float s0 = __shfl(acc, 1), s1 = __shfl(acc, 2), s2 = __shfl(acc, 3);
+  mnx = block_reduce_minmax(mnx, true, s_red);
+  mny = block_reduce_minmax(mny, true, s_red);
+  mxx = block_reduce_minmax(mxx, false, s_red);
+  mxy = block_reduce_minmax(mxy, false, s_red);
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) ct += (unsigned)__shfl_xor((int)ct, off);
+  __syncthreads();
+  if (lane == 0) s_cnt[tid / kWave] = ct;
+  if (chain_wave && lane < 4) s_bc[lane] = acc;
+  __syncthreads();
+  unsigned ctz = 0;
+  for (int w = 0; w < kBlock / kWave; ++w) ctz += s_cnt[w];
+  const float mid = s_bc[0], s0 = s_bc[1], s1 = s_bc[2], s2 = s_bc[3];
 
   int pass = 0;
   if (sz > 2) {
@@ -1551,64 +1604,99 @@ k_cluster_verify_w(const uint32_t* members, const uint32_t* cl_first, const floa
     const float proj_norm = __builtin_sqrtf(m0 * m0 + m1 * m1);
     const float mean_norm = __builtin_sqrtf(m0 * m0 + (m1 * m1 + m2 * m2));
     const float grad = hope_det_asinf(proj_norm / mean_norm);
-    if (!(grad > th_angle)) {  // wave-uniform
-      // ---- pass 2: covariance sums cxx, cxy, cyy (lanes 0..2) ---------------------------
+    if (!(grad > th_angle)) {  // block-uniform
+      // ---- pass 2: covariance sums cxx, cxy, cyy (lanes 0..2) ---------------------------------
       float cacc = 0.f;
-      for (int base = 0; base < sz; base += kVTile) {
-        const int tile = min(kVTile, sz - base);
-        for (int t = lane; t < tile; t += kWave) {
-          const float4 nn = fit_nrm[m[base + t]];
-          const float tx = nn.x - m0, ty = nn.y - m1;
-          s_v[0][t] = tx * tx;
-          s_v[1][t] = tx * ty;
-          s_v[2][t] = ty * ty;
-        }
+      {
+        float4 rn[kVPer];
+        auto fetch = [&](int tile_i) {
+#pragma unroll
+          for (int i = 0; i < kVPer; ++i) {
+            const int e = tile_i * kVTile + i * kBlock + tid;
+            if (e < sz) rn[i] = fit_nrm[m[e]];
+          }
+        };
         __syncthreads();
-        if (lane < 3) {
-          const float* sv = s_v[lane];
-#pragma unroll 8
-          for (int j = 0; j < tile; ++j) cacc += sv[j];
+        fetch(0);
+        for (int ti = 0; ti < n_tiles; ++ti) {
+          const int buf = ti & 1;
+          const int tile = min(kVTile, sz - ti * kVTile);
+#pragma unroll
+          for (int i = 0; i < kVPer; ++i) {
+            const int t = i * kBlock + tid;
+            if (t < tile) {
+              const float tx = rn[i].x - m0, ty = rn[i].y - m1;
+              s_v[buf][0][t] = tx * tx;
+              s_v[buf][1][t] = tx * ty;
+              s_v[buf][2][t] = ty * ty;
+            }
+          }
+          __syncthreads();
+          if (ti + 1 < n_tiles) fetch(ti + 1);
+          if (chain_wave && lane < 3) cacc = chain_sum(s_v[buf][lane], tile, cacc);
         }
-        __syncthreads();
       }
+      __syncthreads();
+      if (chain_wave && lane < 3) s_bc[lane] = cacc;
+      __syncthreads();
       const float denom = (float)(sz - 1);
-      const float cxx = __shfl(cacc, 0) / denom;
-      const float cxy = __shfl(cacc, 1) / denom;
-      const float cyy = __shfl(cacc, 2) / denom;
+      const float cxx = s_bc[0] / denom;
+      const float cxy = s_bc[1] / denom;
+      const float cyy = s_bc[2] / denom;
       float ax, ay;
       principal_axis_2x2(cxx, cxy, cyy, ax, ay);
-      // ---- pass 3: split sums; lanes 0..2 own part 1 (nx, ny, |nz|), lanes 3..5 part 2 ---
+      // ---- pass 3: split sums; lanes 0..2 own part 1 (nx, ny, |nz|), lanes 3..5 part 2 ----------
       float pacc = 0.f;
       unsigned na = 0;
-      const int comp = lane < 3 ? lane : lane - 3;
-      const unsigned char want = lane < 3 ? 1 : 0;
-      for (int base = 0; base < sz; base += kVTile) {
-        const int tile = min(kVTile, sz - base);
-        for (int t = lane; t < tile; t += kWave) {
-          const float4 nn = fit_nrm[m[base + t]];
-          const float tx = nn.x - m0, ty = nn.y - m1;
-          const bool side = (ax * tx + ay * ty > 0.f);
-          s_v[0][t] = nn.x;
-          s_v[1][t] = nn.y;
-          s_v[2][t] = fabsf(nn.z);
-          s_side[t] = side ? 1 : 0;
-          na += side ? 1u : 0u;
-        }
+      {
+        float4 rn[kVPer];
+        auto fetch = [&](int tile_i) {
+#pragma unroll
+          for (int i = 0; i < kVPer; ++i) {
+            const int e = tile_i * kVTile + i * kBlock + tid;
+            if (e < sz) rn[i] = fit_nrm[m[e]];
+          }
+        };
         __syncthreads();
-        if (lane < 6) {
-          const float* sv = s_v[comp];
-          for (int j = 0; j < tile; ++j)
-            if (s_side[j] == want) pacc += sv[j];
+        fetch(0);
+        for (int ti = 0; ti < n_tiles; ++ti) {
+          const int buf = ti & 1;
+          const int tile = min(kVTile, sz - ti * kVTile);
+#pragma unroll
+          for (int i = 0; i < kVPer; ++i) {
+            const int t = i * kBlock + tid;
+            if (t < tile) {
+              const float4 nn = rn[i];
+              const float tx = nn.x - m0, ty = nn.y - m1;
+              const bool side = (ax * tx + ay * ty > 0.f);
+              const float nz = fabsf(nn.z);
+              s_v[buf][0][t] = side ? nn.x : 0.f;
+              s_v[buf][1][t] = side ? nn.y : 0.f;
+              s_v[buf][2][t] = side ? nz : 0.f;
+              s_v[buf][3][t] = side ? 0.f : nn.x;
+              s_v[buf][4][t] = side ? 0.f : nn.y;
+              s_v[buf][5][t] = side ? 0.f : nz;
+              na += side ? 1u : 0u;
+            }
+          }
+          __syncthreads();
+          if (ti + 1 < n_tiles) fetch(ti + 1);
+          if (chain_wave && lane < 6) pacc = chain_sum(s_v[buf][lane], tile, pacc);
         }
-        __syncthreads();
       }
 #pragma unroll
       for (int off = kWave / 2; off > 0; off >>= 1) na += (unsigned)__shfl_xor((int)na, off);
+      __syncthreads();
+      if (lane == 0) s_cnt[tid / kWave] = na;
+      if (chain_wave && lane < 6) s_bc[lane] = pacc;
+      __syncthreads();
+      na = 0;
+      for (int w = 0; w < kBlock / kWave; ++w) na += s_cnt[w];
       const unsigned nb = (unsigned)sz - na;
       if (na != 0 && nb != 0) {
         const float fa = (float)na, fb = (float)nb;
-        const float p1[3] = {__shfl(pacc, 0) / fa, __shfl(pacc, 1) / fa, __shfl(pacc, 2) / fa};
-        const float p2[3] = {__shfl(pacc, 3) / fb, __shfl(pacc, 4) / fb, __shfl(pacc, 5) / fb};
+        const float p1[3] = {s_bc[0] / fa, s_bc[1] / fa, s_bc[2] / fa};
+        const float p2[3] = {s_bc[3] / fb, s_bc[4] / fb, s_bc[5] / fb};
         const float mu = p2[0] * p1[0] + (p2[1] * p1[1] + p2[2] * p1[2]);
         const float n1 = __builtin_sqrtf(sqnorm3(p1));
         const float n2 = __builtin_sqrtf(sqnorm3(p2));
@@ -1617,7 +1705,7 @@ k_cluster_verify_w(const uint32_t* members, const uint32_t* cl_first, const floa
       }
     }
   }
-  if (lane == 0) {
+  if (tid == 0) {
     rec[c].z_mean = mid / (float)ctz;
     rec[c].min_x = mnx;
     rec[c].min_y = mny;
