@@ -137,6 +137,9 @@ class HopeLib:
             f.restype = C.c_int
             f.argtypes = [vp, i32, C.POINTER(C.c_double)]
             self.fn["profile_stage_bytes"] = f
+            f = getattr(self.dll, prefix + "fast_division_active")
+            f.restype, f.argtypes = C.c_int, [vp]
+            self.fn["fast_division_active"] = f
 
     def default_config(self):
         cfg = HopeConfig()
@@ -295,6 +298,9 @@ class HopeContext:
         m = HopeMaxPlane()
         self._check(self.lib.fn["get_max_plane"](self._h, frame, C.byref(m)), "get_max_plane")
         return m
+
+    def fast_division_active(self):
+        return self.lib.fn["fast_division_active"](self._h)
 
     def profile_enable(self, on=True):
         self._check(self.lib.fn["profile_enable"](self._h, 1 if on else 0), "profile_enable")

@@ -128,6 +128,9 @@ struct hope_ctx {
   std::string err;
   double whole_ms = 0, ref_ms = 0;
   int normals_cap_small = 0;  // test knob: force the neighbour-list overflow path
+  int force_ieee_div = 0;     // test knob HOPE_DEBUG_IEEE_DIV
+  int fast_div = 0;           // div_const<true> verified for fast_div_key (the current camera model)
+  float fast_div_key[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   int ablate = 0;             // timing experiments only (HOPE_DEBUG_ABLATE): wrong results
   int pixel_sort = 0;         // test knob: depth frames through the per-pixel sort (the cloud path's voxel stage)
   uint32_t* d_grp_cnt = nullptr;  // depth path: groups per chunk, then its exclusive scan
@@ -345,8 +348,12 @@ inline int launch_bbox(hope_ctx* c, const DepthSrc& src, size_t n_per_frame)
     ALLOC(c->d_grp_off, uint32_t, n_chunks + 1);
     HIPCHK(hipMemsetAsync(c->d_grp_cnt + n_chunks, 0, sizeof(uint32_t), c->stream));
     const unsigned bx = std::max(1u, std::min<unsigned>(nblk(c->cpf, (kBlock / kWave) * 16), 512u));
-    hipLaunchKernelGGL(k_bbox_groups, dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi, c->inv_xy, c->inv_z,
-                       c->cpf, c->d_grp_cnt);
+    if (c->fast_div)
+      hipLaunchKernelGGL(k_bbox_groups<true>, dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi, c->inv_xy,
+                         c->inv_z, c->cpf, c->d_grp_cnt);
+    else
+      hipLaunchKernelGGL(k_bbox_groups<false>, dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi, c->inv_xy,
+                         c->inv_z, c->cpf, c->d_grp_cnt);
   } else if (depth8_ok(src)) {
     const unsigned bx = std::max(1u, std::min<unsigned>(nblk(n_per_frame / 8), 256u));
     hipLaunchKernelGGL(k_bbox_depth8, dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi);
@@ -381,8 +388,12 @@ template <class VK>
 void launch_group_records(hope_ctx* c, const DepthSrc& src, unsigned bx, int cell_bits, VK* rkey, uint32_t* rval,
                           uint4* rec)
 {
-  hipLaunchKernelGGL((k_group_records<VK>), dim3(bx, c->n_frames), dim3(kBlock), 0, c->stream, src, c->d_fi,
-                     c->inv_xy, c->inv_z, cell_bits, c->cpf, c->d_grp_off, rkey, rval, rec);
+  if (c->fast_div)
+    hipLaunchKernelGGL((k_group_records<VK, true>), dim3(bx, c->n_frames), dim3(kBlock), 0, c->stream, src, c->d_fi,
+                       c->inv_xy, c->inv_z, cell_bits, c->cpf, c->d_grp_off, rkey, rval, rec);
+  else
+    hipLaunchKernelGGL((k_group_records<VK, false>), dim3(bx, c->n_frames), dim3(kBlock), 0, c->stream, src, c->d_fi,
+                       c->inv_xy, c->inv_z, cell_bits, c->cpf, c->d_grp_off, rkey, rval, rec);
 }
 template <class VK>
 void launch_group_records(hope_ctx*, const CloudSrc&, unsigned, int, VK*, uint32_t*, uint4*) {}
@@ -392,8 +403,12 @@ void launch_centroids_groups(hope_ctx* c, const DepthSrc& src, const VK* uniq, c
                              const uint32_t* run_cnt, const uint32_t* sval, const uint4* rec, unsigned n_vox,
                              int cell_bits, float4* d_vox, int* d_vox_frame)
 {
-  hipLaunchKernelGGL((k_centroids_groups<VK>), dim3(nblk(n_vox)), dim3(kBlock), 0, c->stream, src, c->d_fi, uniq,
-                     run_start, run_cnt, sval, rec, n_vox, cell_bits, c->cpf, d_vox, d_vox_frame);
+  if (c->fast_div)
+    hipLaunchKernelGGL((k_centroids_groups<VK, true>), dim3(nblk(n_vox)), dim3(kBlock), 0, c->stream, src, c->d_fi,
+                       uniq, run_start, run_cnt, sval, rec, n_vox, cell_bits, c->cpf, d_vox, d_vox_frame);
+  else
+    hipLaunchKernelGGL((k_centroids_groups<VK, false>), dim3(nblk(n_vox)), dim3(kBlock), 0, c->stream, src, c->d_fi,
+                       uniq, run_start, run_cnt, sval, rec, n_vox, cell_bits, c->cpf, d_vox, d_vox_frame);
 }
 template <class VK>
 void launch_centroids_groups(hope_ctx*, const CloudSrc&, const VK*, const uint32_t*, const uint32_t*, const uint32_t*,
@@ -678,6 +693,25 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   return HOPE_OK;
 }
 
+// Decides once per camera model whether the 3-instruction division by a constant reproduces the
+// IEEE quotient on every dividend A1 can produce (k_verify_fast_div); the result is cached.
+int check_fast_div(hope_ctx* c, const DepthSrc& src)
+{
+  const float key[9] = {src.fx, src.fy, src.cx, src.cy, src.scale, src.min_d, src.max_d, (float)src.w, (float)src.h};
+  if (std::memcmp(key, c->fast_div_key, sizeof(key)) == 0) return HOPE_OK;
+  c->fast_div = 0;
+  if (!c->force_ieee_div) {
+    HIPCHK(hipMemsetAsync(&c->d_glob->changed, 0, sizeof(unsigned), c->stream));
+    hipLaunchKernelGGL(k_verify_fast_div, dim3(65536 / kBlock, std::max(src.w, src.h)), dim3(kBlock), 0, c->stream, src,
+                       &c->d_glob->changed);
+    int st = sync_globals(c);
+    if (st != HOPE_OK) return st;
+    c->fast_div = c->h_glob->changed ? 0 : 1;
+  }
+  std::memcpy(c->fast_div_key, key, sizeof(key));
+  return HOPE_OK;
+}
+
 template <class Src>
 int run_pipeline(hope_ctx* c, const Src& src, size_t n_per_frame)
 {
@@ -844,6 +878,8 @@ HOPE_API int hope_create(const hope_config* cfg, hope_ctx** out)
   c->normals_cap_small = (knob && knob[0] == '1') ? 1 : 0;
   knob = std::getenv("HOPE_DEBUG_ABLATE");
   c->ablate = knob ? std::atoi(knob) : 0;
+  knob = std::getenv("HOPE_DEBUG_IEEE_DIV");
+  c->force_ieee_div = (knob && knob[0] == '1') ? 1 : 0;
   knob = std::getenv("HOPE_DEBUG_PIXEL_SORT");
   c->pixel_sort = (knob && knob[0] == '1') ? 1 : 0;
   *out = c;
@@ -930,7 +966,12 @@ HOPE_API int hope_segment_depth_u16(hope_ctx* c, const uint16_t* depth, int w, i
   src.scale = c->cfg.depth_scale;
   src.min_d = c->cfg.min_depth;
   src.max_d = c->cfg.max_depth;
+  src.rcp_fx = 1.0f / src.fx;
+  src.rcp_fy = 1.0f / src.fy;
+  src.rcp_scale = 1.0f / src.scale;
   c->dsrc = src;
+  int st = check_fast_div(c, src);
+  if (st != HOPE_OK) return st;
   return run_pipeline(c, src, ppf);
 }
 
@@ -1142,6 +1183,8 @@ HOPE_API int hope_profile_enable(hope_ctx* c, int on)
   }
   return HOPE_OK;
 }
+
+HOPE_API int hope_fast_division_active(const hope_ctx* c) { return c ? c->fast_div : HOPE_E_INVALID; }
 
 HOPE_API int hope_profile_stage_count(void) { return ST_COUNT; }
 

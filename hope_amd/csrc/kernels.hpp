@@ -56,6 +56,7 @@ struct DepthSrc {
   int w, h;
   unsigned ppf;  // pixels per frame
   float fx, fy, cx, cy, scale, min_d, max_d;
+  float rcp_fx, rcp_fy, rcp_scale;  // 1/fx, 1/fy, 1/scale rounded to float (div_const)
 };
 
 struct CloudSrc {
@@ -434,17 +435,55 @@ __device__ __forceinline__ void writelane_u64(unsigned long long uniform_val, in
       : "s"((int)(unsigned)uniform_val), "s"((int)(unsigned)(uniform_val >> 32)), "s"(uniform_lane));
 }
 
+// a / b for a divisor that is constant over the call.  FAST: one Markstein correction step,
+// q0 = a*(1/b), r = fma(-b, q0, a), q = fma(r, 1/b, q0) -- 3 instructions instead of the ~11 of
+// the IEEE division sequence.  It is only used after k_verify_fast_div has compared it with the
+// IEEE quotient for EVERY dividend the call can produce (65536 depth codes x image columns /
+// rows), so the bits are those of the reference's division by construction.
+template <bool FAST>
+__device__ __forceinline__ float div_const(float a, float b, float rcp_b)
+{
+  if (!FAST) return a / b;
+  const float q0 = a * rcp_b;
+  const float r = __fmaf_rn(-b, q0, a);
+  return __fmaf_rn(r, rcp_b, q0);
+}
+
+// every dividend of A1 for this camera model: fails (sets *fail) if div_const<true> ever differs
+// from the IEEE quotient.  grid = (65536 / kBlock, max(w, h)).
+__global__ void __launch_bounds__(kBlock) k_verify_fast_div(DepthSrc s, unsigned* fail)
+{
+  const unsigned d = blockIdx.x * kBlock + threadIdx.x;
+  const int i = blockIdx.y;
+  if (d > 65535u) return;
+  const float zf = (float)d;
+  const float z = zf / s.scale;
+  bool bad = __float_as_uint(z) != __float_as_uint(div_const<true>(zf, s.scale, s.rcp_scale));
+  if (z < s.max_d && z > s.min_d) {
+    if (i < s.w) {
+      const float a = ((float)i - s.cx) * z;
+      bad |= __float_as_uint(a / s.fx) != __float_as_uint(div_const<true>(a, s.fx, s.rcp_fx));
+    }
+    if (i < s.h) {
+      const float a = ((float)i - s.cy) * z;
+      bad |= __float_as_uint(a / s.fy) != __float_as_uint(div_const<true>(a, s.fy, s.rcp_fy));
+    }
+  }
+  if (bad) *fail = 1u;
+}
+
 // A1..A3 with the pose held in registers (same arithmetic as load_point(DepthSrc))
+template <bool FAST>
 __device__ __forceinline__ bool depth_point(const DepthSrc& s, const float* aff, int frame, unsigned pix, float& ox,
                                             float& oy, float& oz)
 {
   const uint16_t d = s.depth[(size_t)frame * s.ppf + pix];
   const int row = (int)(pix / (unsigned)s.w);
   const int col = (int)(pix - (unsigned)row * (unsigned)s.w);
-  const float z = (float)d / s.scale;
+  const float z = div_const<FAST>((float)d, s.scale, s.rcp_scale);
   if (!(z < s.max_d && z > s.min_d)) return false;
-  const float x = ((float)col - s.cx) * z / s.fx;
-  const float y = ((float)row - s.cy) * z / s.fy;
+  const float x = div_const<FAST>(((float)col - s.cx) * z, s.fx, s.rcp_fx);
+  const float y = div_const<FAST>(((float)row - s.cy) * z, s.fy, s.rcp_fy);
   apply_affine(aff, x, y, z, ox, oy, oz);
   return true;
 }
@@ -517,20 +556,22 @@ __device__ __forceinline__ void chunk_rowcol(unsigned c, int lane, unsigned w, i
 }
 
 // A1..A3 for the pixel at (row, col), pose in registers
+template <bool FAST>
 __device__ __forceinline__ bool depth_point_rc(const DepthSrc& s, const float* aff, int frame, unsigned pix, int row,
                                                int col, float& ox, float& oy, float& oz)
 {
   const uint16_t d = s.depth[(size_t)frame * s.ppf + pix];
-  const float z = (float)d / s.scale;
+  const float z = div_const<FAST>((float)d, s.scale, s.rcp_scale);
   if (!(z < s.max_d && z > s.min_d)) return false;
-  const float x = ((float)col - s.cx) * z / s.fx;
-  const float y = ((float)row - s.cy) * z / s.fy;
+  const float x = div_const<FAST>(((float)col - s.cx) * z, s.fx, s.rcp_fx);
+  const float y = div_const<FAST>(((float)row - s.cy) * z, s.fy, s.rcp_fy);
   apply_affine(aff, x, y, z, ox, oy, oz);
   return true;
 }
 
 // Pass 1: bbox + survivor count per frame (getMinMax3D) and the number of groups per chunk.
 // Groups are found on the un-shifted cell triple floor(p * inv_leaf), which needs no bbox.
+template <bool FAST>
 __global__ void __launch_bounds__(kBlock)
 k_bbox_groups(DepthSrc src, FrameInfo* fi, float inv_xy, float inv_z, unsigned cpf, uint32_t* grp_cnt)
 {
@@ -549,7 +590,7 @@ k_bbox_groups(DepthSrc src, FrameInfo* fi, float inv_xy, float inv_z, unsigned c
     int row, col;
     chunk_rowcol(c, lane, (unsigned)src.w, row, col);
     float x = 0.f, y = 0.f, z = 0.f;
-    const bool ok = pix < src.ppf && depth_point_rc(src, aff, frame, pix, row, col, x, y, z);
+    const bool ok = pix < src.ppf && depth_point_rc<FAST>(src, aff, frame, pix, row, col, x, y, z);
     const float gx = floorf(x * inv_xy), gy = floorf(y * inv_xy), gz = floorf(z * inv_z);
     if (ok) {
       mn[0] = fminf(mn[0], x);
@@ -605,7 +646,7 @@ k_bbox_groups(DepthSrc src, FrameInfo* fi, float inv_xy, float inv_z, unsigned c
 
 // Pass 2: one record per group: sort key = frame << cell_bits | PCL voxel index, payload =
 // (global chunk id, 64-bit pixel mask).  grp_off = exclusive scan of pass 1's counts.
-template <class KeyT>
+template <class KeyT, bool FAST>
 __global__ void __launch_bounds__(kBlock)
 k_group_records(DepthSrc src, const FrameInfo* fi, float inv_xy, float inv_z, int cell_bits, unsigned cpf,
                 const uint32_t* grp_off, KeyT* rkey, uint32_t* rval, uint4* rec)
@@ -627,7 +668,7 @@ k_group_records(DepthSrc src, const FrameInfo* fi, float inv_xy, float inv_z, in
     int row, col;
     chunk_rowcol(c, lane, (unsigned)src.w, row, col);
     float x = 0.f, y = 0.f, z = 0.f;
-    const bool ok = pix < src.ppf && depth_point_rc(src, aff, frame, pix, row, col, x, y, z);
+    const bool ok = pix < src.ppf && depth_point_rc<FAST>(src, aff, frame, pix, row, col, x, y, z);
     const float gx = floorf(x * inv_xy), gy = floorf(y * inv_xy), gz = floorf(z * inv_z);
     unsigned long long my_grp;
     chunk_groups<true>(ok, gx, gy, gz, my_grp);
@@ -645,7 +686,7 @@ k_group_records(DepthSrc src, const FrameInfo* fi, float inv_xy, float inv_z, in
 
 // Centroids from the sorted group records: one lane per voxel, records in sorted (= chunk)
 // order, mask bits from 0 upwards.
-template <class KeyT>
+template <class KeyT, bool FAST>
 __global__ void __launch_bounds__(kBlock)
 k_centroids_groups(DepthSrc src, const FrameInfo* fi, const KeyT* unique, const uint32_t* run_start,
                    const uint32_t* run_count, const uint32_t* sval, const uint4* rec, unsigned n_vox, int cell_bits,
@@ -670,7 +711,7 @@ k_centroids_groups(DepthSrc src, const FrameInfo* fi, const KeyT* unique, const 
       const int b = __ffsll((long long)m) - 1;
       m &= m - 1ull;
       float x = 0.f, y = 0.f, z = 0.f;
-      depth_point(src, aff, frame, base + (unsigned)b, x, y, z);
+      depth_point<FAST>(src, aff, frame, base + (unsigned)b, x, y, z);
       sx += x;
       sy += y;
       sz += z;

@@ -181,6 +181,11 @@ HOPE_API int hope_profile_stage(hope_ctx* ctx, int stage, const char** name, dou
  * the sizes of the calls made while enabled) moved by the same timed regions */
 HOPE_API int hope_profile_stage_bytes(hope_ctx* ctx, int stage, double* alg_bytes);
 
+/* 1 if the last depth call used the 3-instruction division by the camera constants (it is
+ * enabled only after an exhaustive on-device comparison with the IEEE quotient for every
+ * dividend the camera model can produce), 0 if it used IEEE divisions */
+HOPE_API int hope_fast_division_active(const hope_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

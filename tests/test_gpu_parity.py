@@ -195,6 +195,32 @@ def test_depth_frames_through_the_per_pixel_sort(hip_lib, oracle_lib, monkeypatc
         assert_frame_equal(o, g2, f)
 
 
+def test_division_by_camera_constants(hip_lib, oracle_lib, monkeypatch):
+    """A1's divisions by depth_scale / fx / fy run as a 3-instruction sequence once the library has
+    checked it against the IEEE quotient for every possible dividend; the knob forces IEEE divisions.
+    Both must give the oracle's bits, also for intrinsics other than TUM's."""
+    depth, t, q = synth_frames(2, first=60)
+    monkeypatch.setenv("HOPE_DEBUG_IEEE_DIV", "1")
+    g_ieee = HopeContext(hip_lib)
+    monkeypatch.delenv("HOPE_DEBUG_IEEE_DIV")
+    g_fast, o = HopeContext(hip_lib), HopeContext(oracle_lib)
+    for c in (g_ieee, g_fast, o):
+        c.set_frame_poses(t, q)
+        assert c.segment_depth(depth) == 0
+    assert g_ieee.fast_division_active() == 0
+    assert g_fast.fast_division_active() == 1      # TUM intrinsics pass the exhaustive check
+    for f in range(2):
+        assert_frame_equal(o, g_ieee, f, check_transformed=True)
+        assert_frame_equal(o, g_fast, f, check_transformed=True)
+    for kw in (dict(fx=525.0, fy=525.5, cx=319.5, cy=239.5, depth_scale=1000.0), dict(fx=450.3, fy=451.7, cx=300.1, cy=250.9, depth_scale=4999.0)):
+        g2, o2 = both(hip_lib, oracle_lib, **kw)
+        for c in (g2, o2):
+            c.set_frame_poses(t, q)
+            c.segment_depth(depth)
+        for f in range(2):
+            assert_frame_equal(o2, g2, f, check_transformed=True)
+
+
 def test_odd_image_shapes(hip_lib, oracle_lib):
     """Widths that are not a multiple of the 64-pixel chunk, a ragged last chunk, tiny images."""
     depth, t, q = synth_frames(2, first=40)
