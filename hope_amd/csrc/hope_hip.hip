@@ -128,6 +128,8 @@ struct hope_ctx {
   std::string err;
   double whole_ms = 0, ref_ms = 0;
   int normals_cap_small = 0;  // test knob: force the neighbour-list overflow path
+  unsigned knn_fine_limit = 4096;  // more left-over k-NN queries than this build the coarse index (test knob)
+  unsigned n_knn_todo = 0;
   int force_ieee_div = 0;     // test knob HOPE_DEBUG_IEEE_DIV
   int fast_div = 0;           // div_const<true> verified for fast_div_key (the current camera model)
   float fast_div_key[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -193,7 +195,7 @@ void derive_thresholds(hope_ctx* c)
   const double radius = (double)norm_r;
   c->radius = norm_r;
   c->r2 = static_cast<float>(radius * radius);  // KdTreeFLANN::radiusSearch
-  c->ring = (int)std::floor(norm_r * c->inv_xy + 0.01f) + 1;
+  c->ring = (int)std::floor(norm_r * c->inv_xy + 0.01f) + 1;  // = 2 = kHaloNormals for the reference's 1.01 * th_xy
 }
 
 // Eigen Quaternion::toRotationMatrix on the un-normalised quaternion (transform.cpp:168-171)
@@ -583,15 +585,70 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   int* knn;
   ALLOC(knn, int, (size_t)n_fit * K);
   c->d_knn = knn;
+  uint32_t* todo;
+  ALLOC(todo, uint32_t, n_fit);
   pm = prof_mark(c);
+  HIPCHK(hipMemsetAsync(&c->d_glob->n_todo, 0, sizeof(unsigned), s));
   if (K <= 8) {
     hipLaunchKernelGGL((k_knn_tile<8>), tile_grid, dim3(kBlock), 0, s, spt, col_first, fit_rank, c->d_fi, c->inv_xy,
-                       c->inv_z, c->cfg.th_xy, K, knn, (c->ablate / 10) % 10);
+                       c->inv_z, c->cfg.th_xy, K, knn, todo, &c->d_glob->n_todo, (c->ablate / 10) % 10);
   } else {
     hipLaunchKernelGGL((k_knn_tile<kMaxKnn>), tile_grid, dim3(kBlock), 0, s, spt, col_first, fit_rank, c->d_fi,
-                       c->inv_xy, c->inv_z, c->cfg.th_xy, K, knn, (c->ablate / 10) % 10);
+                       c->inv_xy, c->inv_z, c->cfg.th_xy, K, knn, todo, &c->d_glob->n_todo, (c->ablate / 10) % 10);
   }
   prof_close(c, ST_KNN, pm, 16.0 * n_vox + 4.0 * K * (double)n_fit);
+  {
+    int st = sync_globals(c);
+    if (st != HOPE_OK) return st;
+  }
+  const unsigned n_todo = c->h_glob->n_todo;
+  c->n_knn_todo = n_todo;
+  if (n_todo > 0) {
+    // queries whose neighbours lie outside their LDS tile: a whole-frame ring expansion, over the
+    // fine index when they are few, over a coarse index of the fit points when they are many
+    pm = prof_mark(c);
+    const unsigned gt = nblk(n_todo, kBlock / kWave);  // one wave per query
+    if (n_todo <= std::max(c->knn_fine_limit, c->knn_fine_limit ? n_fit / 16 : 0u)) {
+      if (K <= 8)
+        hipLaunchKernelGGL((k_knn_todo<GlobalCols, 8>), dim3(gt), dim3(kBlock), 0, s, todo, &c->d_glob->n_todo, fit_pt,
+                           fit_frame, spt, col_first, fit_rank, c->d_fi, c->inv_xy, c->inv_z, c->cfg.th_xy, 1, K, knn);
+      else
+        hipLaunchKernelGGL((k_knn_todo<GlobalCols, kMaxKnn>), dim3(gt), dim3(kBlock), 0, s, todo, &c->d_glob->n_todo,
+                           fit_pt, fit_frame, spt, col_first, fit_rank, c->d_fi, c->inv_xy, c->inv_z, c->cfg.th_xy, 1,
+                           K, knn);
+    } else {
+      const unsigned total_ccols = c->h_glob->total_ccols;
+      CK *qk_in, *qk_out;
+      uint32_t *qv_in, *qv_out, *ccol_first;
+      float4* cspt;
+      ALLOC(qk_in, CK, n_fit);
+      ALLOC(qk_out, CK, n_fit);
+      ALLOC(qv_in, uint32_t, n_fit);
+      ALLOC(qv_out, uint32_t, n_fit);
+      ALLOC(ccol_first, uint32_t, (size_t)total_ccols + 1);
+      ALLOC(cspt, float4, n_fit);
+      hipLaunchKernelGGL((k_coarse_keys<CK>), dim3(nblk(n_fit)), dim3(kBlock), 0, s, fit_pt, fit_frame, c->d_fi, n_fit,
+                         c->inv_xy, c->inv_z, zbits, qk_in, qv_in);
+      const int cbits = zbits + bits_for(total_ccols);
+      if (sizeof(CK) == 4) {
+        HIPCHK(sort_pairs_u32(pa, (const uint32_t*)qk_in, (uint32_t*)qk_out, qv_in, qv_out, n_fit, cbits, s));
+      } else {
+        HIPCHK(sort_pairs_u64(pa, (const uint64_t*)qk_in, (uint64_t*)qk_out, qv_in, qv_out, n_fit, cbits, s));
+      }
+      hipLaunchKernelGGL((k_column_table<CK>), dim3(nblk((size_t)total_ccols + 1)), dim3(kBlock), 0, s, qk_out, n_fit,
+                         total_ccols, zbits, ccol_first);
+      hipLaunchKernelGGL(k_gather_coarse, dim3(nblk(n_fit)), dim3(kBlock), 0, s, fit_pt, qv_out, n_fit, cspt);
+      if (K <= 8)
+        hipLaunchKernelGGL((k_knn_todo<CoarseCols, 8>), dim3(gt), dim3(kBlock), 0, s, todo, &c->d_glob->n_todo, fit_pt,
+                           fit_frame, cspt, ccol_first, nullptr, c->d_fi, c->inv_xy, c->inv_z, c->cfg.th_xy, kCoarse, K,
+                           knn);
+      else
+        hipLaunchKernelGGL((k_knn_todo<CoarseCols, kMaxKnn>), dim3(gt), dim3(kBlock), 0, s, todo, &c->d_glob->n_todo,
+                           fit_pt, fit_frame, cspt, ccol_first, nullptr, c->d_fi, c->inv_xy, c->inv_z, c->cfg.th_xy,
+                           kCoarse, K, knn);
+    }
+    prof_close(c, ST_KNN, pm, (16.0 + 4.0 * K) * (double)n_todo);
+  }
   // ---- A9 region growing as min-rank reachability -----------------------------------
   int *rank, *seed_node, *parent, *L, *root, *label;
   ALLOC(rank, int, n_fit);
@@ -878,6 +935,8 @@ HOPE_API int hope_create(const hope_config* cfg, hope_ctx** out)
   c->normals_cap_small = (knob && knob[0] == '1') ? 1 : 0;
   knob = std::getenv("HOPE_DEBUG_ABLATE");
   c->ablate = knob ? std::atoi(knob) : 0;
+  knob = std::getenv("HOPE_DEBUG_KNN_FINE_LIMIT");
+  if (knob) c->knn_fine_limit = (unsigned)std::atoll(knob);
   knob = std::getenv("HOPE_DEBUG_IEEE_DIV");
   c->force_ieee_div = (knob && knob[0] == '1') ? 1 : 0;
   knob = std::getenv("HOPE_DEBUG_PIXEL_SORT");

@@ -18,6 +18,7 @@ namespace hope {
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
 constexpr int kMaxKnn = 32;
+constexpr int kCoarse = 8;   // coarse k-NN index: columns of kCoarse x kCoarse cells
 
 // Per-frame state, resident in HBM for the whole call (one per depth frame / cloud).
 struct FrameInfo {
@@ -31,6 +32,7 @@ struct FrameInfo {
   long long cells;      // div_b product
   float slack;          // float-rounding slack of a column index, in cells (kNN bound)
   int col_off;          // first entry of this frame in the column table
+  int ccol_off;         // first entry in the coarse (8x8 columns) table of the fit points
   int vox_start, n_vox; // range in the global down-sampled arrays
   int fit_start, n_fit; // range in the global normal-filtered arrays
   int seg_start, n_segments;
@@ -49,6 +51,8 @@ struct Globals {  // scalars produced on device, read back at the sync points
   unsigned int pad;
   unsigned int n_groups;  // depth path: number of (chunk, voxel) group records
   unsigned int max_tiles; // largest per-frame count of 16x16-column tiles (neighbours.hpp)
+  unsigned int total_ccols;  // entries of the coarse column table
+  unsigned int n_todo;       // k-NN queries left over by the tile pass
 };
 
 struct DepthSrc {
@@ -195,19 +199,20 @@ __global__ void __launch_bounds__(1024) k_frame_grid(FrameInfo* fi, int n_frames
   // scan of the per-frame column-table sizes
   __shared__ unsigned s_scan[1024];
   __shared__ unsigned long long s_max_cells;
-  __shared__ unsigned s_max_dz, s_any_over, s_carry, s_max_tiles;
+  __shared__ unsigned s_max_dz, s_any_over, s_carry, s_carry2, s_max_tiles;
   const int tid = threadIdx.x;
   if (tid == 0) {
     s_max_cells = 1;
     s_max_dz = 1;
     s_any_over = 0;
     s_carry = 0;
+    s_carry2 = 0;
     s_max_tiles = 0;
   }
   __syncthreads();
   for (int base = 0; base < n_frames; base += 1024) {
     const int f = base + tid;
-    unsigned ncols = 0;
+    unsigned ncols = 0, nccols = 0;
     if (f < n_frames) {
       FrameInfo& F = fi[f];
       int min_b[3] = {0, 0, 0}, div_b[3] = {0, 0, 0};
@@ -215,6 +220,7 @@ __global__ void __launch_bounds__(1024) k_frame_grid(FrameInfo* fi, int n_frames
       long long cells = 0;
       float slack = 0.f;
       ncols = 1;
+      nccols = 1;
       if (F.n_raw > 0) {
         const float inv[3] = {inv_xy, inv_xy, inv_z};
         long long dxyz = 1;
@@ -238,6 +244,7 @@ __global__ void __launch_bounds__(1024) k_frame_grid(FrameInfo* fi, int n_frames
           atomicMax(&s_max_cells, (unsigned long long)cells);
           atomicMax(&s_max_dz, (unsigned)div_b[2]);
           ncols = (unsigned)(div_b[0] * div_b[1]) + 1u;
+          nccols = (unsigned)(((div_b[0] + kCoarse - 1) / kCoarse) * ((div_b[1] + kCoarse - 1) / kCoarse)) + 1u;
           atomicMax(&s_max_tiles, (unsigned)(((div_b[0] + 15) / 16) * ((div_b[1] + 15) / 16)));
         }
       }
@@ -263,6 +270,20 @@ __global__ void __launch_bounds__(1024) k_frame_grid(FrameInfo* fi, int n_frames
     __syncthreads();
     if (tid == 1023) s_carry = carry + s_scan[1023];
     __syncthreads();
+    // the same scan for the coarse column table
+    s_scan[tid] = nccols;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const unsigned add = tid >= off ? s_scan[tid - off] : 0u;
+      __syncthreads();
+      s_scan[tid] += add;
+      __syncthreads();
+    }
+    const unsigned carry2 = s_carry2;
+    if (f < n_frames) fi[f].ccol_off = (int)(carry2 + s_scan[tid] - nccols);
+    __syncthreads();
+    if (tid == 1023) s_carry2 = carry2 + s_scan[1023];
+    __syncthreads();
   }
   if (tid == 0) {
     g->max_cells = s_max_cells;
@@ -270,6 +291,7 @@ __global__ void __launch_bounds__(1024) k_frame_grid(FrameInfo* fi, int n_frames
     g->max_div_z = s_max_dz;
     g->any_overflow = s_any_over;
     g->max_tiles = s_max_tiles;
+    g->total_ccols = s_carry2;
   }
 }
 
@@ -913,6 +935,40 @@ k_gather_sorted(const float4* vox, const uint32_t* svals, unsigned n_vox, float4
   float4 p = vox[v];
   p.w = __uint_as_float(v);
   spt[s] = p;
+}
+
+// ---- coarse index over the FIT points only (k-NN queries that leave the LDS tile) -------------
+// Same layout as the column index, with columns of kCoarse x kCoarse cells: a ring of coarse
+// columns covers kCoarse times the distance per table lookup, and points that failed the
+// normal gate are not in it at all.
+template <class KeyT>
+__global__ void __launch_bounds__(kBlock)
+k_coarse_keys(const float4* fit_pt, const int* fit_frame, const FrameInfo* fi, unsigned n_fit, float inv_xy,
+              float inv_z, int zbits, KeyT* keys, uint32_t* vals)
+{
+  const unsigned g = blockIdx.x * kBlock + threadIdx.x;
+  if (g >= n_fit) return;
+  const FrameInfo& F = fi[fit_frame[g]];
+  const float4 p = fit_pt[g];
+  const int cx = clampi(cell_unclamped(p.x, inv_xy, F.min_b[0]), 0, F.div_b[0] - 1) / kCoarse;
+  const int cy = clampi(cell_unclamped(p.y, inv_xy, F.min_b[1]), 0, F.div_b[1] - 1) / kCoarse;
+  const int cz = clampi(cell_unclamped(p.z, inv_z, F.min_b[2]), 0, F.div_b[2] - 1);
+  const int dxc = (F.div_b[0] + kCoarse - 1) / kCoarse;
+  const unsigned col = (unsigned)F.ccol_off + (unsigned)(cy * dxc + cx);
+  keys[g] = ((KeyT)col << zbits) | (KeyT)(unsigned)cz;
+  vals[g] = g;
+}
+
+// sorted copy of the fit points: xyz + fit rank in .w
+__global__ void __launch_bounds__(kBlock)
+k_gather_coarse(const float4* fit_pt, const uint32_t* svals, unsigned n_fit, float4* cspt)
+{
+  const unsigned s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= n_fit) return;
+  const uint32_t v = svals[s];
+  float4 p = fit_pt[v];
+  p.w = __int_as_float((int)v);
+  cspt[s] = p;
 }
 
 // FLANN L2_Simple<float>: ((dx*dx + dy*dy) + dz*dz)

@@ -25,7 +25,9 @@ constexpr int kHaloKnn = 4;                // k-NN: rings 0..4 are served from L
 constexpr int kTileCap = 1536;             // points (tile + halo) held in LDS: 24 KiB
 constexpr int kRunDirect = 24;             // a stencil row with at most this many points is scanned whole
 
-struct GlobalCols {  // the whole frame, straight from HBM
+template <bool W_IS_RANK>
+struct GlobalColsT {  // a column index straight from HBM: W_IS_RANK false = every down-sampled point
+                      // (.w = PCL-order index), true = the coarse index of the fit points (.w = fit rank)
   const float4* spt;
   const uint32_t* col_first;
   const int* fit_rank;
@@ -45,9 +47,14 @@ struct GlobalCols {  // the whole frame, straight from HBM
     hi = col_first[c + cx1 + 1];
   }
   __device__ __forceinline__ float4 pt(unsigned e) const { return spt[e]; }
-  __device__ __forceinline__ int fit(unsigned, const float4& p) const { return fit_rank[__float_as_uint(p.w)]; }
+  __device__ __forceinline__ int fit(unsigned, const float4& p) const
+  {
+    return W_IS_RANK ? __float_as_int(p.w) : fit_rank[__float_as_uint(p.w)];
+  }
   static constexpr bool kLds = false;
 };
+typedef GlobalColsT<false> GlobalCols;
+typedef GlobalColsT<true> CoarseCols;
 
 template <int HALO>
 struct TileCols {  // LDS copy of a tile and its halo
@@ -82,36 +89,49 @@ struct TileShared {
   unsigned rowl[kTW + 1];   // local start (prefix of segment sizes)
   unsigned intg[kTile + 1]; // global start of each interior row segment
   unsigned intp[kTile + 1]; // prefix of interior row sizes
+  unsigned colg[kTW * kTW]; // slab mode: global start of the slab part of each column
+  unsigned zext[2];         // slab mode: ordered-int min / max z of the region
+  unsigned total;
 };
 
 struct TileGeom {
   int x0, x1, y0, y1;      // interior columns [x0,x1) x [y0,y1)
   int xh0, xh1, yh0, yh1;  // with halo, clamped to the grid
-  unsigned total;          // points in tile + halo
-  unsigned n_int;          // points in the interior
+  unsigned total;          // points in the LDS copy (tile + halo)
+  unsigned n_int;          // points in the interior (all z)
   bool in_lds;             // the LDS copy is valid
+  bool slab;               // the copy is a z slab: interior points also need z0 <= z < z1
+  float z0, z1;
 };
 
-// Loads the size x size column tile at (x0, y0) of frame F with its halo.  Returns false if the
-// tile holds no point; g.in_lds tells whether the LDS copy was made (it fits) or not.
+__device__ __forceinline__ void tile_extent(const FrameInfo& F, int x0, int y0, int size, int halo, TileGeom& g)
+{
+  const int dx = F.div_b[0], dy = F.div_b[1];
+  g.x0 = x0;
+  g.y0 = y0;
+  g.x1 = min(x0 + size, dx);
+  g.y1 = min(y0 + size, dy);
+  g.xh0 = max(g.x0 - halo, 0);
+  g.yh0 = max(g.y0 - halo, 0);
+  g.xh1 = min(g.x1 + halo, dx);
+  g.yh1 = min(g.y1 + halo, dy);
+  g.slab = false;
+  g.z0 = -INFINITY;
+  g.z1 = INFINITY;
+}
+
+// Loads the size x size column tile at (x0, y0) of frame F with its halo, every z.  Returns
+// false if the tile holds no point; g.in_lds tells whether the LDS copy was made (it fits).
 template <bool WITH_FIT, int HALO>
 __device__ __forceinline__ bool load_tile(const FrameInfo& F, int x0, int y0, int size, const float4* spt,
                                           const uint32_t* col_first, const int* fit_rank,
                                           TileShared<WITH_FIT, HALO>& S, TileGeom& g)
 {
-  constexpr int kHalo = HALO;
   constexpr int kTabStride = TileShared<WITH_FIT, HALO>::kTabStride;
   const int tid = threadIdx.x;
-  const int dx = F.div_b[0], dy = F.div_b[1];
+  const int dx = F.div_b[0];
   __syncthreads();  // the previous tile of this block is done with S
-  g.x0 = x0;
-  g.y0 = y0;
-  g.x1 = min(g.x0 + size, dx);
-  g.y1 = min(g.y0 + size, dy);
-  g.xh0 = max(g.x0 - kHalo, 0);
-  g.yh0 = max(g.y0 - kHalo, 0);
-  g.xh1 = min(g.x1 + kHalo, dx);
-  g.yh1 = min(g.y1 + kHalo, dy);
+  tile_extent(F, x0, y0, size, HALO, g);
   const int rows = g.yh1 - g.yh0, width = g.xh1 - g.xh0, irows = g.y1 - g.y0;
   const unsigned col_off = (unsigned)F.col_off;
   if (tid < rows) {
@@ -178,37 +198,303 @@ __device__ __forceinline__ void interior_point(const TileShared<WITH_FIT, HALO>&
   e_loc = S.rowl[rh] + (e_glob - S.rowg[rh]);
 }
 
-// Runs body(g) for the 16x16 tile `tile` of frame F, or, when the tile and its halo hold more
-// points than the LDS copy (several z layers per column: noisy far range, walls), for its 8x8
-// and then 4x4 sub-tiles; a 4x4 sub-tile that still does not fit is handed to body with
-// g.in_lds == false (the global accessor).  Every branch is block-uniform.
-template <bool WITH_FIT, int HALO, class Body>
-__device__ __forceinline__ void tile_cascade(const FrameInfo& F, int tile, const float4* spt, const uint32_t* col_first,
-                                             const int* fit_rank, TileShared<WITH_FIT, HALO>& S, Body&& body)
+// first entry of [lo, hi) of the sorted array with z >= zt (a column ascends in z up to one cell)
+__device__ __forceinline__ unsigned lower_bound_z_glob(const float4* spt, unsigned lo, unsigned hi, float zt)
+{
+  while (lo < hi) {
+    const unsigned mid = (lo + hi) >> 1;
+    if (spt[mid].z < zt) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// min / max z over the columns of the region with halo (first / last entry of every column)
+template <bool WITH_FIT, int HALO>
+__device__ __forceinline__ bool region_z_extent(const FrameInfo& F, const TileGeom& g, const float4* spt,
+                                                const uint32_t* col_first, TileShared<WITH_FIT, HALO>& S, float& zmin,
+                                                float& zmax, unsigned& count)
+{
+  const int tid = threadIdx.x;
+  const int dx = F.div_b[0];
+  const int rows = g.yh1 - g.yh0, width = g.xh1 - g.xh0;
+  __syncthreads();
+  if (tid == 0) {
+    S.zext[0] = 0xffffffffu;
+    S.zext[1] = 0u;
+    S.total = 0u;
+  }
+  __syncthreads();
+  unsigned lo_o = 0xffffffffu, hi_o = 0u, cnt = 0u;
+  for (int c = tid; c < rows * width; c += kBlock) {
+    const int r = c / width, cc = c - r * width;
+    const unsigned col = (unsigned)F.col_off + (unsigned)((g.yh0 + r) * dx + g.xh0 + cc);
+    const unsigned a = col_first[col], b = col_first[col + 1];
+    if (b > a) {
+      lo_o = min(lo_o, f2ord(spt[a].z));
+      hi_o = max(hi_o, f2ord(spt[b - 1].z));
+      cnt += b - a;
+    }
+  }
+  if (cnt) {
+    atomicMin(&S.zext[0], lo_o);
+    atomicMax(&S.zext[1], hi_o);
+    atomicAdd(&S.total, cnt);
+  }
+  __syncthreads();
+  count = S.total;
+  if (count == 0) return false;
+  zmin = ord2f(S.zext[0]);
+  zmax = ord2f(S.zext[1]);
+  return true;
+}
+
+// Loads the z slab [zlo_h, zhi_h) of the region: every column is cut by two binary searches on
+// z and the pieces are packed in (row, column) order, so that a stencil row is still one
+// contiguous run and the column table works as in load_tile.  g.total > kTileCap: not loaded.
+template <bool WITH_FIT, int HALO>
+__device__ __forceinline__ void load_slab(const FrameInfo& F, float zlo_h, float zhi_h, const float4* spt,
+                                          const uint32_t* col_first, const int* fit_rank,
+                                          TileShared<WITH_FIT, HALO>& S, TileGeom& g)
+{
+  constexpr int kTabStride = TileShared<WITH_FIT, HALO>::kTabStride;
+  const int tid = threadIdx.x;
+  const int dx = F.div_b[0];
+  const int rows = g.yh1 - g.yh0, width = g.xh1 - g.xh0;
+  const int nc = rows * width;
+  __syncthreads();
+  for (int c = tid; c < nc; c += kBlock) {
+    const int r = c / width, cc = c - r * width;
+    const unsigned col = (unsigned)F.col_off + (unsigned)((g.yh0 + r) * dx + g.xh0 + cc);
+    unsigned a = col_first[col], b = col_first[col + 1];
+    if (b > a) {
+      a = lower_bound_z_glob(spt, a, b, zlo_h);
+      b = lower_bound_z_glob(spt, a, b, zhi_h);
+    }
+    S.colg[c] = a;
+    S.tab[r * kTabStride + cc] = b - a;
+  }
+  __syncthreads();
+  if (tid < kWave) {  // exclusive scan of the nc counts in (row, column) order by one wave
+    const int per = (nc + kWave - 1) / kWave;
+    const int c0 = tid * per, c1 = min(c0 + per, nc);
+    unsigned sum = 0;
+    for (int c = c0; c < c1; ++c) sum += S.tab[(c / width) * kTabStride + (c % width)];
+    unsigned incl = sum;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const unsigned o = (unsigned)__shfl_up((int)incl, off);
+      if (tid >= off) incl += o;
+    }
+    unsigned run = incl - sum;
+    for (int c = c0; c < c1; ++c) {
+      unsigned* t = &S.tab[(c / width) * kTabStride + (c % width)];
+      const unsigned n = *t;
+      *t = run;
+      run += n;
+    }
+    if (tid == kWave - 1) S.total = incl;
+  }
+  __syncthreads();
+  g.total = S.total;
+  g.in_lds = g.total <= (unsigned)kTileCap;
+  g.slab = true;
+  g.n_int = g.total;
+  for (int r = tid; r < rows; r += kBlock)
+    S.tab[r * kTabStride + width] = (r + 1 < rows) ? S.tab[(r + 1) * kTabStride] : g.total;
+  __syncthreads();
+  if (!g.in_lds || g.total == 0) return;
+  for (unsigned i = tid; i < g.total; i += kBlock) {
+    // row: last one whose start is <= i; column likewise inside the row
+    int r = 0;
+    while (r + 1 < rows && S.tab[(r + 1) * kTabStride] <= i) ++r;
+    const unsigned* t = &S.tab[r * kTabStride];
+    int cc = 0;
+    while (cc + 1 < width && t[cc + 1] <= i) ++cc;
+    float4 p = spt[S.colg[r * width + cc] + (i - t[cc])];
+    if (WITH_FIT) p.w = __int_as_float(fit_rank[__float_as_uint(p.w)]);
+    S.pt[i] = p;
+  }
+  __syncthreads();
+}
+
+// Walks the regions of one 16x16 tile that fit in LDS, one per call of next():
+//   * the whole tile with its halo, every z (horizontal surfaces: a few points per column), else
+//   * its 8x8 quarters, every z (noisy far range: several z layers per column), and a quarter
+//     that still does not fit
+//   * in z slabs (walls, clutter): interior [z, z + h cells), halo zhalo on both sides; a slab
+//     that does not fit halves h; at h = 1 the quarter is split into 4x4 regions, whose one-cell
+//     slabs always fit (a cell holds one down-sampled point).
+// Written as a state machine so that the caller's per-region body exists once in the kernel.
+// Every decision is block-uniform.
+template <bool WITH_FIT, int HALO>
+struct TileWalker {
+  const FrameInfo& F;
+  const float4* spt;
+  const uint32_t* col_first;
+  const int* fit_rank;
+  TileShared<WITH_FIT, HALO>& S;
+  int halo_xy;   // xy halo of the slab regions (<= HALO)
+  float zhalo, leaf_z;
+  int X0, Y0;
+  int stage = 0, a = 0, b = 0;
+  bool in8 = false, in4 = false, in4walk = false;
+  int x8 = 0, y8 = 0, x4 = 0, y4 = 0, h8 = 1, h4 = 1;
+  float z8 = 0.f, zend8 = 0.f, zs8 = 0.f, ze8 = 0.f, z4 = 0.f, zend4 = 0.f;
+
+  __device__ __forceinline__ TileWalker(const FrameInfo& F_, int tile, int halo_xy_, float zhalo_, float leaf_z_,
+                                        const float4* spt_, const uint32_t* col_first_, const int* fit_rank_,
+                                        TileShared<WITH_FIT, HALO>& S_)
+      : F(F_), spt(spt_), col_first(col_first_), fit_rank(fit_rank_), S(S_), halo_xy(halo_xy_), zhalo(zhalo_),
+        leaf_z(leaf_z_)
+  {
+    const int ntx = (F.div_b[0] + kTile - 1) / kTile;
+    const int ty = tile / ntx;
+    X0 = (tile - ty * ntx) * kTile;
+    Y0 = ty * kTile;
+  }
+
+  // slab height (cells) from the mean number of points per z layer of the region
+  __device__ __forceinline__ int slab_cells(unsigned count, float zmin, float zmax) const
+  {
+    const float layers = fmaxf((zmax - zmin) / leaf_z + 1.f, 1.f);
+    const float per_layer = fmaxf((float)count / layers, 1e-3f);
+    return (int)fminf(fmaxf(0.6f * (float)kTileCap / per_layer - 2.f * zhalo / leaf_z, 1.f), 65536.f);
+  }
+
+  __device__ bool next(TileGeom& g)
+  {
+    for (int guard = 0; guard < (1 << 22); ++guard) {
+      if (stage == 0) {
+        stage = 1;
+        if (!load_tile<WITH_FIT, HALO>(F, X0, Y0, kTile, spt, col_first, fit_rank, S, g)) break;
+        if (g.in_lds) {
+          stage = 2;
+          return true;
+        }
+        continue;
+      }
+      if (stage == 2) break;
+      if (in4) {
+        if (!in4walk) {
+          if (b == 4) {
+            in4 = false;
+            z8 = ze8;
+            continue;
+          }
+          x4 = x8 + (b & 1) * 4;
+          y4 = y8 + (b >> 1) * 4;
+          ++b;
+          if (x4 >= F.div_b[0] || y4 >= F.div_b[1]) continue;
+          tile_extent(F, x4, y4, 4, halo_xy, g);
+          float zmin, zmax;
+          unsigned count;
+          if (!region_z_extent<WITH_FIT, HALO>(F, g, spt, col_first, S, zmin, zmax, count)) continue;
+          z4 = fmaxf(zs8, zmin - 1.5f * leaf_z);
+          zend4 = ze8;
+          h4 = slab_cells(count, zmin, zmax);
+          in4walk = true;
+        }
+        if (!(z4 < zend4)) {
+          in4walk = false;
+          continue;
+        }
+        const float z1 = fminf(z4 + (float)h4 * leaf_z, zend4);
+        tile_extent(F, x4, y4, 4, halo_xy, g);
+        load_slab<WITH_FIT, HALO>(F, z4 - zhalo, z1 + zhalo, spt, col_first, fit_rank, S, g);
+        if (!g.in_lds && h4 > 1) {
+          h4 = max(h4 / 2, 1);
+          continue;
+        }
+        g.z0 = z4;
+        g.z1 = z1;
+        z4 = z1;
+        if (g.in_lds && g.total == 0) continue;
+        return true;  // (in_lds false here cannot happen; the caller then reads from the global arrays)
+      }
+      if (in8) {
+        if (!(z8 < zend8)) {
+          in8 = false;
+          continue;
+        }
+        const float z1 = fminf(z8 + (float)h8 * leaf_z, zend8);
+        tile_extent(F, x8, y8, 8, halo_xy, g);
+        load_slab<WITH_FIT, HALO>(F, z8 - zhalo, z1 + zhalo, spt, col_first, fit_rank, S, g);
+        if (!g.in_lds) {
+          if (h8 > 1) {
+            h8 = max(h8 / 2, 1);
+            continue;
+          }
+          in4 = true;
+          in4walk = false;
+          b = 0;
+          zs8 = z8;
+          ze8 = z1;
+          continue;
+        }
+        g.z0 = z8;
+        g.z1 = z1;
+        z8 = z1;
+        if (g.total == 0) continue;
+        return true;
+      }
+      if (a == 4) break;
+      x8 = X0 + (a & 1) * 8;
+      y8 = Y0 + (a >> 1) * 8;
+      ++a;
+      if (x8 >= F.div_b[0] || y8 >= F.div_b[1]) continue;
+      if (!load_tile<WITH_FIT, HALO>(F, x8, y8, 8, spt, col_first, fit_rank, S, g)) continue;
+      if (g.in_lds) return true;
+      tile_extent(F, x8, y8, 8, halo_xy, g);
+      float zmin, zmax;
+      unsigned count;
+      if (!region_z_extent<WITH_FIT, HALO>(F, g, spt, col_first, S, zmin, zmax, count)) continue;
+      z8 = zmin - 1.5f * leaf_z;
+      zend8 = zmax + 1.5f * leaf_z;
+      h8 = slab_cells(count, zmin, zmax);
+      in8 = true;
+    }
+    stage = 2;
+    return false;
+  }
+};
+
+// Calls fn_lds(q, cqx, cqy) for every interior point of the tile / slab, q taken from the LDS
+// copy.  A slab that could not be loaded (cannot happen with one point per cell; handled exactly
+// anyway) calls fn_glob instead, with q from the sorted array (.w = PCL-order index).
+template <bool WITH_FIT, int HALO, class FnLds, class FnGlob>
+__device__ __forceinline__ void for_each_interior(const FrameInfo& F, const TileGeom& g,
+                                                  const TileShared<WITH_FIT, HALO>& S, const float4* spt,
+                                                  const uint32_t* col_first, float inv_xy, float leaf_z,
+                                                  FnLds&& fn_lds, FnGlob&& fn_glob)
 {
   const int dx = F.div_b[0], dy = F.div_b[1];
-  const int ntx = (dx + kTile - 1) / kTile;
-  const int ty = tile / ntx, tx = tile - ty * ntx;
-  const int X0 = tx * kTile, Y0 = ty * kTile;
-  TileGeom g;
-  if (!load_tile<WITH_FIT, HALO>(F, X0, Y0, kTile, spt, col_first, fit_rank, S, g)) return;
   if (g.in_lds) {
-    body(g);
-    return;
-  }
-  for (int a = 0; a < 4; ++a) {
-    const int x8 = X0 + (a & 1) * 8, y8 = Y0 + (a >> 1) * 8;
-    if (x8 >= dx || y8 >= dy) continue;
-    if (!load_tile<WITH_FIT, HALO>(F, x8, y8, 8, spt, col_first, fit_rank, S, g)) continue;
-    if (g.in_lds) {
-      body(g);
-      continue;
+    const unsigned n_iter = g.slab ? g.total : g.n_int;
+    for (unsigned i = threadIdx.x; i < n_iter; i += kBlock) {
+      unsigned el = i;
+      if (!g.slab) {
+        unsigned eg;
+        interior_point(S, g, i, eg, el);
+      }
+      const float4 q = S.pt[el];
+      const int cqx = clampi(cell_unclamped(q.x, inv_xy, F.min_b[0]), 0, dx - 1);
+      const int cqy = clampi(cell_unclamped(q.y, inv_xy, F.min_b[1]), 0, dy - 1);
+      if (g.slab && !(cqx >= g.x0 && cqx < g.x1 && cqy >= g.y0 && cqy < g.y1 && q.z >= g.z0 && q.z < g.z1)) continue;
+      fn_lds(q, cqx, cqy);
     }
-    for (int b = 0; b < 4; ++b) {
-      const int x4 = x8 + (b & 1) * 4, y4 = y8 + (b >> 1) * 4;
-      if (x4 >= dx || y4 >= dy) continue;
-      if (!load_tile<WITH_FIT, HALO>(F, x4, y4, 4, spt, col_first, fit_rank, S, g)) continue;
-      body(g);
+  } else {
+    const int w = g.x1 - g.x0;
+    for (int c = threadIdx.x; c < w * (g.y1 - g.y0); c += kBlock) {
+      const int cx = g.x0 + c % w, cy = g.y0 + c / w;
+      const unsigned col = (unsigned)F.col_off + (unsigned)(cy * dx + cx);
+      unsigned a = col_first[col];
+      const unsigned b = col_first[col + 1];
+      a = lower_bound_z_glob(spt, a, b, g.z0 - 2.5f * leaf_z);
+      for (unsigned e = a; e < b; ++e) {
+        const float4 q = spt[e];
+        if (q.z >= g.z1 + 2.5f * leaf_z) break;
+        if (q.z >= g.z0 && q.z < g.z1) fn_glob(q, cx, cy);
+      }
     }
   }
 }
@@ -420,25 +706,23 @@ k_normals_tile(const float4* spt, const uint32_t* col_first, const FrameInfo* fi
   const float leaf_z = 1.0f / inv_z;
   unsigned short* cand_e = s_cand_e + threadIdx.x;
   const GlobalCols gc{spt, col_first, nullptr, (unsigned)F.col_off, dx};
-  tile_cascade<false, kHaloNormals>(F, (int)blockIdx.x, spt, col_first, nullptr, S, [&](const TileGeom& g) {
-    if (ablate == 1) return;
-    const bool lds = g.in_lds && ring <= kHaloNormals;
+  const float zhalo = radius + 2.5f * leaf_z;
+  TileWalker<false, kHaloNormals> walk(F, (int)blockIdx.x, kHaloNormals, zhalo, leaf_z, spt, col_first, nullptr, S);
+  TileGeom g;
+  while (walk.next(g)) {
+    if (ablate == 1) continue;
     const TileCols<kHaloNormals> tc{S.pt, S.tab, g.xh0, g.yh0};
-    for (unsigned i = threadIdx.x; i < g.n_int; i += kBlock) {
-      unsigned eg, el;
-      interior_point(S, g, i, eg, el);
-      const float4 q = spt[eg];
-      const int cqx = clampi(cell_unclamped(q.x, inv_xy, F.min_b[0]), 0, dx - 1);
-      const int cqy = clampi(cell_unclamped(q.y, inv_xy, F.min_b[1]), 0, dy - 1);
-      float4 out;
-      if (lds)
-        out = estimate_normal<TileCols<kHaloNormals>, CAPL>(tc, q, cqx, cqy, dx, dy, ring, radius, r2, leaf_z, cand_e,
-                                                            ablate);
-      else
-        out = estimate_normal<GlobalCols, CAPL>(gc, q, cqx, cqy, dx, dy, ring, radius, r2, leaf_z, cand_e, ablate);
-      normals[__float_as_uint(q.w)] = out;
-    }
-  });
+    for_each_interior(
+        F, g, S, spt, col_first, inv_xy, leaf_z,
+        [&](const float4& q, int cqx, int cqy) {
+          normals[__float_as_uint(q.w)] = estimate_normal<TileCols<kHaloNormals>, CAPL>(
+              tc, q, cqx, cqy, dx, dy, ring, radius, r2, leaf_z, cand_e, ablate);
+        },
+        [&](const float4& q, int cqx, int cqy) {
+          normals[__float_as_uint(q.w)] =
+              estimate_normal<GlobalCols, CAPL>(gc, q, cqx, cqy, dx, dy, ring, radius, r2, leaf_z, cand_e, ablate);
+        });
+  }
 }
 
 // ---- A8: exact k nearest neighbours among the fit points ---------------------------------------
@@ -534,10 +818,15 @@ __device__ __forceinline__ bool knn_rings(const Cols& cols, const float4 q, int 
   return false;
 }
 
+constexpr uint32_t kTodoFromRing0 = 0x80000000u;  // todo flag: only part of rings 0..2 has been seen
+
+// Phase A, grid = (max tiles per frame, n_frames): every query whose k neighbours provably lie
+// inside the LDS copy of its tile is answered here; the others (sparse neighbourhoods) are
+// appended to `todo` and answered by k_knn_todo.
 template <int KMAX>
 __global__ void __launch_bounds__(kBlock)
 k_knn_tile(const float4* spt, const uint32_t* col_first, const int* fit_rank, const FrameInfo* fi, float inv_xy,
-           float inv_z, float cell_xy, int K, int* knn_out, int ablate)
+           float inv_z, float cell_xy, int K, int* knn_out, uint32_t* todo, unsigned* n_todo, int ablate)
 {
   typedef TileCols<kHaloKnn> Tc;
   __shared__ TileShared<true, kHaloKnn> S;
@@ -546,54 +835,190 @@ k_knn_tile(const float4* spt, const uint32_t* col_first, const int* fit_rank, co
   if (F.n_fit <= 0 || (int)blockIdx.x >= ((dx + kTile - 1) / kTile) * ((dy + kTile - 1) / kTile)) return;
   const float leaf_z = 1.0f / inv_z;
   const int k = min(K, F.n_fit);
-  const GlobalCols gc{spt, col_first, fit_rank, (unsigned)F.col_off, dx};
   // Fast pass: the 5x5 square is ring 2; a list that settles there holds only neighbours closer
   // than reach2, so a z window of that height loses nothing.
   const float reach2 = ring_reach(2, F.slack, cell_xy);
-  tile_cascade<true, kHaloKnn>(F, (int)blockIdx.x, spt, col_first, fit_rank, S, [&](const TileGeom& g) {
+  const float zwin = reach2 + 1.5f * leaf_z;
+  TileWalker<true, kHaloKnn> walk(F, (int)blockIdx.x, 2, zwin + leaf_z, leaf_z, spt, col_first, fit_rank, S);
+  TileGeom g;
+  while (walk.next(g)) {
     const Tc tc{S.pt, S.tab, g.xh0, g.yh0};
-    if (ablate == 1) return;
-    for (unsigned i = threadIdx.x; i < g.n_int; i += kBlock) {
-      unsigned eg, el;
-      interior_point(S, g, i, eg, el);
-      const float4 q = spt[eg];
+    if (ablate == 1) continue;
+    auto leftover = [&](const float4& q, int, int) {
       const int me = fit_rank[__float_as_uint(q.w)];
-      if (me < 0) continue;
-      const int cqx = clampi(cell_unclamped(q.x, inv_xy, F.min_b[0]), 0, dx - 1);
-      const int cqy = clampi(cell_unclamped(q.y, inv_xy, F.min_b[1]), 0, dy - 1);
+      if (me < 0) return;
+      for (int j = 0; j < K; ++j) knn_out[(size_t)me * K + j] = -1;
+      todo[atomicAdd(n_todo, 1u)] = (uint32_t)me | kTodoFromRing0;
+    };
+    for_each_interior(F, g, S, spt, col_first, inv_xy, leaf_z, [&](const float4& q, int cqx, int cqy) {
+      const int me = __float_as_int(q.w);
+      if (me < 0) return;
       knn_key lst[KMAX];
 #pragma unroll
       for (int j = 0; j < KMAX; ++j) lst[j] = kKnnEmpty;
       const int max_ring = max(max(cqx, dx - 1 - cqx), max(cqy, dy - 1 - cqy));
       bool done = false;
-      int next_ring = 0;
-      if (g.in_lds) {
-        if (reach2 > 0.f) {
-          const int x0 = max(cqx - 2, 0), x1 = min(cqx + 2, dx - 1);
-          const float zlo = q.z - reach2 - 1.5f * leaf_z, zhi = q.z + reach2 + 1.5f * leaf_z;
-          for (int cy = max(cqy - 2, 0); cy <= min(cqy + 2, dy - 1); ++cy)
-            for_window(tc, x0, x1, cy, zlo, zhi,
-                       [&](unsigned e, const float4& p) { knn_offer<Tc, KMAX>(tc, q, e, p, k, lst); });
-          done = knn_kth<KMAX>(k, lst) < reach2 * reach2 * 0.999999f;
-        }
-        if (ablate == 2) done = true;
-        if (!done) {
-          // sparse neighbourhood: the exact ring expansion over the LDS copy (every z; points the
-          // fast pass has already listed are skipped), then over the whole frame
-          done = knn_rings<Tc, KMAX, true>(tc, q, cqx, cqy, dx, dy, 0, min(kHaloKnn, max_ring), k, F.slack, cell_xy,
-                                           leaf_z, lst);
-          next_ring = kHaloKnn + 1;
-        }
+      if (reach2 > 0.f) {
+        const int x0 = max(cqx - 2, 0), x1 = min(cqx + 2, dx - 1);
+        const float zlo = q.z - zwin, zhi = q.z + zwin;
+        for (int cy = max(cqy - 2, 0); cy <= min(cqy + 2, dy - 1); ++cy)
+          for_window(tc, x0, x1, cy, zlo, zhi,
+                     [&](unsigned e, const float4& p) { knn_offer<Tc, KMAX>(tc, q, e, p, k, lst); });
+        done = knn_kth<KMAX>(k, lst) < reach2 * reach2 * 0.999999f;
       }
-      if (ablate == 3) done = true;
-      if (!done && next_ring <= max_ring)
-        knn_rings<GlobalCols, KMAX, false>(gc, q, cqx, cqy, dx, dy, next_ring, max_ring, k, F.slack, cell_xy, leaf_z,
-                                           lst);
+      if (ablate == 2) done = true;
+      if (!done && !g.slab) {
+        // sparse neighbourhood: the exact ring expansion over the LDS copy (every z; points the
+        // fast pass has already listed are skipped)
+        done = knn_rings<Tc, KMAX, true>(tc, q, cqx, cqy, dx, dy, 0, min(kHaloKnn, max_ring), k, F.slack, cell_xy,
+                                         leaf_z, lst);
+        if (max_ring <= kHaloKnn) done = true;  // every column of the frame has been visited
+      }
+      // settled: the answer; not settled: the list so far, which phase B takes up again
 #pragma unroll
       for (int j = 0; j < KMAX; ++j)
         if (j < K) knn_out[(size_t)me * K + j] = (j < k) ? (int)(unsigned)lst[j] : -1;
+      if (!done) todo[atomicAdd(n_todo, 1u)] = (uint32_t)me | (g.slab ? kTodoFromRing0 : 0u);
+    }, leftover);
+  }
+}
+
+// Phase B: the queries of `todo`, one WAVE each, by ring expansion over a whole-frame column
+// index: the fine index of all points (few queries; rings 0..kHaloKnn are done unless flagged) or
+// the coarse index of the fit points (many queries).  The 64 lanes take the columns of a ring in
+// parallel, each keeping a private sorted list of candidates that beat the current k-th
+// distance; the private lists are then merged, smallest first, into the list every lane holds.
+// A far search therefore costs one memory round trip per ring instead of one per column.  The
+// list phase A left in knn_out is taken up again (distances recomputed), so the z windows are
+// narrow from the first ring on; points already listed are skipped.
+template <int KMAX>
+__device__ __forceinline__ void knn_insert(knn_key key, int k, knn_key (&lst)[KMAX])
+{
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j)
+    if (j == k - 1) lst[j] = key;
+#pragma unroll
+  for (int j = KMAX - 1; j >= 1; --j) {
+    if (j < k) {
+      const knn_key a = lst[j - 1], b = lst[j];
+      const bool sw = b < a;
+      lst[j - 1] = sw ? b : a;
+      lst[j] = sw ? a : b;
     }
-  });
+  }
+}
+
+__device__ __forceinline__ knn_key wave_min_key(knn_key v)
+{
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, off);
+    const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), off);
+    const knn_key o = ((knn_key)hi << 32) | lo;
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+template <class Cols, int KMAX>
+__global__ void __launch_bounds__(kBlock)
+k_knn_todo(const uint32_t* todo, const unsigned* n_todo, const float4* fit_pt, const int* fit_frame,
+           const float4* idx_pt, const uint32_t* idx_first, const int* fit_rank, const FrameInfo* fi, float inv_xy,
+           float inv_z, float cell_xy, int coarse, int K, int* knn_out)
+{
+  const unsigned t = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;  // wave-uniform
+  if (t >= *n_todo) return;
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t entry = todo[t];
+  const int me = (int)(entry & ~kTodoFromRing0);
+  const FrameInfo& F = fi[fit_frame[me]];
+  const float4 q = fit_pt[me];
+  const int dx = (F.div_b[0] + coarse - 1) / coarse, dy = (F.div_b[1] + coarse - 1) / coarse;
+  const int cqx = clampi(cell_unclamped(q.x, inv_xy, F.min_b[0]), 0, F.div_b[0] - 1) / coarse;
+  const int cqy = clampi(cell_unclamped(q.y, inv_xy, F.min_b[1]), 0, F.div_b[1] - 1) / coarse;
+  const int k = min(K, F.n_fit);
+  const float leaf_z = 1.0f / inv_z;
+  // a coarse column is `coarse` cells wide; the rounding slack of a cell index shrinks with it
+  const float slack = F.slack / (float)coarse + (coarse > 1 ? 1e-6f : 0.f);
+  const float cell = cell_xy * (float)coarse;
+  const Cols cols{idx_pt, idx_first, fit_rank, (unsigned)(coarse > 1 ? F.ccol_off : F.col_off), dx};
+  knn_key lst[KMAX];  // the same in every lane
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) {
+    lst[j] = kKnnEmpty;
+    if (j < k) {
+      const int r = knn_out[(size_t)me * K + j];
+      if (r >= 0) {
+        const float4 p = fit_pt[r];
+        lst[j] = ((knn_key)__float_as_uint(dist2(q.x, q.y, q.z, p.x, p.y, p.z)) << 32) | (unsigned)r;
+      }
+    }
+  }
+  const int max_ring = max(max(cqx, dx - 1 - cqx), max(cqy, dy - 1 - cqy));
+  const int first_ring = (coarse > 1 || (entry & kTodoFromRing0)) ? 0 : kHaloKnn + 1;
+  for (int R = first_ring; R <= max_ring; ++R) {
+    const int x0 = cqx - R, x1 = cqx + R, y0 = cqy - R, y1 = cqy + R;
+    const int side = 2 * R + 1;
+    const int n_pos = R == 0 ? 1 : 8 * R;
+    const knn_key worst = knn_worst<KMAX>(k, lst);
+    const float wd = key_dist(worst);
+    const float rz = wd < INFINITY ? __builtin_sqrtf(wd) * 1.000001f + 1.5f * leaf_z : INFINITY;
+    const float zlo = q.z - rz, zhi = q.z + rz;
+    knn_key mine[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) mine[j] = kKnnEmpty;
+    for (int pos = lane; pos < n_pos; pos += kWave) {
+      int cx, cy;
+      if (pos < side) {
+        cx = x0 + pos;
+        cy = y0;
+      } else if (pos < 2 * side) {
+        cx = x0 + (pos - side);
+        cy = y1;
+      } else if (pos < 2 * side + (side - 2)) {
+        cx = x0;
+        cy = y0 + 1 + (pos - 2 * side);
+      } else {
+        cx = x1;
+        cy = y0 + 1 + (pos - 2 * side - (side - 2));
+      }
+      if (cx < 0 || cx >= dx || cy < 0 || cy >= dy) continue;
+      unsigned lo, hi;
+      cols.range(cx, cy, lo, hi);
+      if (hi - lo > 8u) lo = lower_bound_z(cols, lo, hi, zlo);
+      for (unsigned e = lo; e < hi; ++e) {
+        const float4 p = cols.pt(e);
+        if (p.z > zhi) break;
+        const int pr = cols.fit(e, p);
+        if (pr < 0) continue;
+        const knn_key key = ((knn_key)__float_as_uint(dist2(q.x, q.y, q.z, p.x, p.y, p.z)) << 32) | (unsigned)pr;
+        if (!(key < worst) || !(key < knn_worst<KMAX>(k, mine))) continue;
+        bool dup = false;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) dup |= (lst[j] == key);
+        if (dup) continue;
+        knn_insert<KMAX>(key, k, mine);
+      }
+    }
+    // merge: at most k of this ring's candidates can enter, taken in ascending order
+    for (int it = 0; it < k; ++it) {
+      const knn_key gmin = wave_min_key(mine[0]);
+      if (!(gmin < knn_worst<KMAX>(k, lst))) break;
+      knn_insert<KMAX>(gmin, k, lst);
+      if (mine[0] == gmin) {  // keys are unique per point: exactly one lane owns it
+#pragma unroll
+        for (int j = 0; j + 1 < KMAX; ++j) mine[j] = mine[j + 1];
+        mine[KMAX - 1] = kKnnEmpty;
+      }
+    }
+    const float reach = ring_reach(R, slack, cell);
+    if (reach > 0.f && knn_kth<KMAX>(k, lst) < reach * reach * 0.999999f) break;
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j)
+      if (j < K) knn_out[(size_t)me * K + j] = (j < k) ? (int)(unsigned)lst[j] : -1;
+  }
 }
 
 }  // namespace hope

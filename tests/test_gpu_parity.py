@@ -195,6 +195,31 @@ def test_depth_frames_through_the_per_pixel_sort(hip_lib, oracle_lib, monkeypatc
         assert_frame_equal(o, g2, f)
 
 
+def test_knn_leftovers_through_the_coarse_index(hip_lib, oracle_lib, monkeypatch):
+    """k-NN queries that the LDS tile cannot settle go through a whole-frame ring expansion: over the
+    fine column index when few, over the coarse index of the fit points when many.  The knob sets the
+    limit to 0 so that every left-over query takes the coarse path; same bits either way."""
+    from hope_amd import synth
+    depth, t, q = synth_frames(2, first=70)
+    xyz = synth.make_multilevel_cloud(300000, first_index=777, device="cpu").numpy()
+    monkeypatch.setenv("HOPE_DEBUG_KNN_FINE_LIMIT", "0")
+    g_coarse = HopeContext(hip_lib)
+    monkeypatch.setenv("HOPE_DEBUG_KNN_FINE_LIMIT", "1000000000")
+    g_fine = HopeContext(hip_lib)
+    monkeypatch.delenv("HOPE_DEBUG_KNN_FINE_LIMIT")
+    o = HopeContext(oracle_lib)
+    for c in (g_coarse, g_fine, o):
+        c.set_frame_poses(t, q)
+        assert c.segment_depth(depth) == 0
+    for f in range(2):
+        assert_frame_equal(o, g_coarse, f)
+        assert_frame_equal(o, g_fine, f)
+    for c in (g_coarse, g_fine, o):
+        assert c.segment_cloud(xyz) == 0
+    assert_frame_equal(o, g_coarse, 0)
+    assert_frame_equal(o, g_fine, 0)
+
+
 def test_division_by_camera_constants(hip_lib, oracle_lib, monkeypatch):
     """A1's divisions by depth_scale / fx / fy run as a 3-instruction sequence once the library has
     checked it against the IEEE quotient for every possible dividend; the knob forces IEEE divisions.
