@@ -1578,14 +1578,17 @@ k_cluster_verify(const uint32_t* members, const uint32_t* cl_first, const float4
 // ---- K10 (block per cluster) --------------------------------------------------------------
 // Same sequential sums as k_cluster_verify, organised for the hardware.  The reference's sums are
 // chains of dependent float adds in member order; a chain cannot be split, but the work around it
-// can: all 256 threads fetch the members' points / normals (coalesced index loads, 16-byte
-// gathers) and park the per-point terms in LDS, double-buffered, while the lanes of wave 0 that
-// own an accumulator run their chains over the previous tile with 16-byte LDS reads.  A chain
-// then costs about one dependent add (4 cycles) per member instead of a memory round trip.
-// Terms that the reference skips (a non-finite z, the other side of the split) enter as +0.0f,
-// which leaves a running sum that started at +0.0f bit-identical.
-constexpr int kVTile = 1024;
-constexpr int kVPer = kVTile / kBlock;
+// can: waves 1..3 of the block are LOADERS -- they fetch the members' points / normals (coalesced
+// index loads one tile ahead, 16-byte gathers) and park the per-point terms in LDS, double
+// buffered -- while wave 0 only runs the chains, one lane per accumulator, over the previous tile
+// with 16-byte LDS reads.  A chain then costs about one dependent add (4 cycles) per member
+// instead of a memory round trip, which matters for the one huge cluster (a floor) that bounds
+// the kernel.  Terms that the reference skips (a non-finite z, the other side of the split)
+// enter as +0.0f, which leaves a running sum that started at +0.0f bit-identical.
+constexpr int kVTile = 1152;                      // members per tile
+constexpr int kVLoaders = kBlock - kWave;         // 192 loader threads
+constexpr int kVPer = kVTile / kVLoaders;         // 6 members per loader thread per tile
+constexpr int kVStride = kVTile + 4;              // LDS row stride: the 6 chain lanes hit different banks
 
 __device__ __forceinline__ float chain_sum(const float* sv, int n, float acc)
 {
@@ -1604,6 +1607,63 @@ __device__ __forceinline__ float chain_sum(const float* sv, int n, float acc)
   return acc;
 }
 
+// One pass over the members: loaders call term(point, normal, slot) for every member of a tile,
+// wave 0 sums rows 0..n_chains-1 of the tile in member order.  Returns this lane's chain sum.
+template <bool NEED_POINT, class Term>
+__device__ __forceinline__ float verify_pass(const uint32_t* m, int sz, const float4* fit_pt, const float4* fit_nrm,
+                                             float (*s_v)[6][kVStride], int n_chains, Term&& term)
+{
+  const int tid = threadIdx.x;
+  const bool loader = tid >= kWave;
+  const int lt = tid - kWave;
+  const int lane = tid & (kWave - 1);
+  const int n_tiles = (sz + kVTile - 1) / kVTile;
+  float acc = 0.f;
+  unsigned idx[kVPer];
+  float4 rp[kVPer], rn[kVPer];
+  auto fetch_idx = [&](int ti) {
+#pragma unroll
+    for (int i = 0; i < kVPer; ++i) {
+      const int e = ti * kVTile + i * kVLoaders + lt;
+      idx[i] = e < sz ? m[e] : 0u;
+    }
+  };
+  auto fetch_data = [&]() {
+#pragma unroll
+    for (int i = 0; i < kVPer; ++i) {
+      if (NEED_POINT) rp[i] = fit_pt[idx[i]];
+      rn[i] = fit_nrm[idx[i]];
+    }
+  };
+  __syncthreads();
+  if (loader) {
+    fetch_idx(0);
+    fetch_data();
+    if (n_tiles > 1) fetch_idx(1);
+  }
+  for (int ti = 0; ti < n_tiles; ++ti) {
+    const int buf = ti & 1;
+    const int tile = min(kVTile, sz - ti * kVTile);
+    if (loader) {
+#pragma unroll
+      for (int i = 0; i < kVPer; ++i) {
+        const int t = i * kVLoaders + lt;
+        if (t < tile) term(rp[i], rn[i], &s_v[buf][0][t]);
+      }
+    }
+    __syncthreads();
+    if (loader) {
+      if (ti + 1 < n_tiles) {
+        fetch_data();                              // tile ti+1, indices already here
+        if (ti + 2 < n_tiles) fetch_idx(ti + 2);
+      }
+    } else if (lane < n_chains) {
+      acc = chain_sum(s_v[buf][lane], tile, acc);
+    }
+  }
+  return acc;
+}
+
 __device__ __forceinline__ float block_reduce_minmax(float v, bool is_min, float* s_red)
 {
 #pragma unroll
@@ -1619,11 +1679,23 @@ __device__ __forceinline__ float block_reduce_minmax(float v, bool is_min, float
   return r;
 }
 
+__device__ __forceinline__ unsigned block_sum_u32(unsigned v, unsigned* s_cnt)
+{
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) v += (unsigned)__shfl_xor((int)v, off);
+  __syncthreads();
+  if ((threadIdx.x & (kWave - 1)) == 0) s_cnt[threadIdx.x / kWave] = v;
+  __syncthreads();
+  unsigned r = 0;
+  for (int w = 0; w < kBlock / kWave; ++w) r += s_cnt[w];
+  return r;
+}
+
 __global__ void __launch_bounds__(kBlock)
 k_cluster_verify_b(const uint32_t* members, const uint32_t* cl_first, const float4* fit_pt, const float4* fit_nrm,
                    unsigned n_cl, float th_angle, ClusterRec* rec)
 {
-  __shared__ __attribute__((aligned(16))) float s_v[2][6][kVTile];
+  __shared__ __attribute__((aligned(16))) float s_v[2][6][kVStride];
   __shared__ float s_bc[8];
   __shared__ float s_red[kBlock / kWave];
   __shared__ unsigned s_cnt[kBlock / kWave];
@@ -1634,64 +1706,30 @@ k_cluster_verify_b(const uint32_t* members, const uint32_t* cl_first, const floa
   const bool chain_wave = tid < kWave;
   const uint32_t* m = members + cl_first[c];
   const int sz = rec[c].size;
-  const int n_tiles = (sz + kVTile - 1) / kVTile;
 
-  // ---- pass 1: sum z (lane 0), sum nx, ny, |nz| (lanes 1..3); bbox + finite count in parallel ----
-  float acc = 0.f;
+  // ---- pass 1: sum z (lane 0), sum nx, ny, |nz| (lanes 1..3); bbox + finite count by the loaders --
   unsigned ct = 0;
   float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
-  {
-    float4 rp[kVPer], rn[kVPer];
-    auto fetch = [&](int tile_i) {
-#pragma unroll
-      for (int i = 0; i < kVPer; ++i) {
-        const int e = tile_i * kVTile + i * kBlock + tid;
-        if (e < sz) {
-          const unsigned g = m[e];
-          rp[i] = fit_pt[g];
-          rn[i] = fit_nrm[g];
-        }
-      }
-    };
-    fetch(0);
-    for (int ti = 0; ti < n_tiles; ++ti) {
-      const int buf = ti & 1;
-      const int tile = min(kVTile, sz - ti * kVTile);
-#pragma unroll
-      for (int i = 0; i < kVPer; ++i) {
-        const int t = i * kBlock + tid;
-        if (t < tile) {
-          const float4 p = rp[i];
-          const float4 nn = rn[i];
-          const bool fin = isfinite(p.z);
-          s_v[buf][0][t] = fin ? p.z : 0.f;
-          s_v[buf][1][t] = nn.x;
-          s_v[buf][2][t] = nn.y;
-          s_v[buf][3][t] = fabsf(nn.z);
-          ct += fin ? 1u : 0u;
-          mnx = fminf(mnx, p.x);
-          mny = fminf(mny, p.y);
-          mxx = fmaxf(mxx, p.x);
-          mxy = fmaxf(mxy, p.y);
-        }
-      }
-      __syncthreads();
-      if (ti + 1 < n_tiles) fetch(ti + 1);
-      if (chain_wave && lane < 4) acc = chain_sum(s_v[buf][lane], tile, acc);
-    }
-  }
+  float acc = verify_pass<true>(m, sz, fit_pt, fit_nrm, s_v, 4, [&](const float4& p, const float4& nn, float* slot) {
+    const bool fin = isfinite(p.z);
+    slot[0 * kVStride] = fin ? p.z : 0.f;
+    slot[1 * kVStride] = nn.x;
+    slot[2 * kVStride] = nn.y;
+    slot[3 * kVStride] = fabsf(nn.z);
+    ct += fin ? 1u : 0u;
+    mnx = fminf(mnx, p.x);
+    mny = fminf(mny, p.y);
+    mxx = fmaxf(mxx, p.x);
+    mxy = fmaxf(mxy, p.y);
+  });
   mnx = block_reduce_minmax(mnx, true, s_red);
   mny = block_reduce_minmax(mny, true, s_red);
   mxx = block_reduce_minmax(mxx, false, s_red);
   mxy = block_reduce_minmax(mxy, false, s_red);
-#pragma unroll
-  for (int off = kWave / 2; off > 0; off >>= 1) ct += (unsigned)__shfl_xor((int)ct, off);
+  const unsigned ctz = block_sum_u32(ct, s_cnt);
   __syncthreads();
-  if (lane == 0) s_cnt[tid / kWave] = ct;
   if (chain_wave && lane < 4) s_bc[lane] = acc;
   __syncthreads();
-  unsigned ctz = 0;
-  for (int w = 0; w < kBlock / kWave; ++w) ctz += s_cnt[w];
   const float mid = s_bc[0], s0 = s_bc[1], s1 = s_bc[2], s2 = s_bc[3];
 
   int pass = 0;
@@ -1703,36 +1741,13 @@ k_cluster_verify_b(const uint32_t* members, const uint32_t* cl_first, const floa
     const float grad = hope_det_asinf(proj_norm / mean_norm);
     if (!(grad > th_angle)) {  // block-uniform
       // ---- pass 2: covariance sums cxx, cxy, cyy (lanes 0..2) ---------------------------------
-      float cacc = 0.f;
-      {
-        float4 rn[kVPer];
-        auto fetch = [&](int tile_i) {
-#pragma unroll
-          for (int i = 0; i < kVPer; ++i) {
-            const int e = tile_i * kVTile + i * kBlock + tid;
-            if (e < sz) rn[i] = fit_nrm[m[e]];
-          }
-        };
-        __syncthreads();
-        fetch(0);
-        for (int ti = 0; ti < n_tiles; ++ti) {
-          const int buf = ti & 1;
-          const int tile = min(kVTile, sz - ti * kVTile);
-#pragma unroll
-          for (int i = 0; i < kVPer; ++i) {
-            const int t = i * kBlock + tid;
-            if (t < tile) {
-              const float tx = rn[i].x - m0, ty = rn[i].y - m1;
-              s_v[buf][0][t] = tx * tx;
-              s_v[buf][1][t] = tx * ty;
-              s_v[buf][2][t] = ty * ty;
-            }
-          }
-          __syncthreads();
-          if (ti + 1 < n_tiles) fetch(ti + 1);
-          if (chain_wave && lane < 3) cacc = chain_sum(s_v[buf][lane], tile, cacc);
-        }
-      }
+      const float cacc =
+          verify_pass<false>(m, sz, fit_pt, fit_nrm, s_v, 3, [&](const float4&, const float4& nn, float* slot) {
+            const float tx = nn.x - m0, ty = nn.y - m1;
+            slot[0 * kVStride] = tx * tx;
+            slot[1 * kVStride] = tx * ty;
+            slot[2 * kVStride] = ty * ty;
+          });
       __syncthreads();
       if (chain_wave && lane < 3) s_bc[lane] = cacc;
       __syncthreads();
@@ -1743,52 +1758,24 @@ k_cluster_verify_b(const uint32_t* members, const uint32_t* cl_first, const floa
       float ax, ay;
       principal_axis_2x2(cxx, cxy, cyy, ax, ay);
       // ---- pass 3: split sums; lanes 0..2 own part 1 (nx, ny, |nz|), lanes 3..5 part 2 ----------
-      float pacc = 0.f;
       unsigned na = 0;
-      {
-        float4 rn[kVPer];
-        auto fetch = [&](int tile_i) {
-#pragma unroll
-          for (int i = 0; i < kVPer; ++i) {
-            const int e = tile_i * kVTile + i * kBlock + tid;
-            if (e < sz) rn[i] = fit_nrm[m[e]];
-          }
-        };
-        __syncthreads();
-        fetch(0);
-        for (int ti = 0; ti < n_tiles; ++ti) {
-          const int buf = ti & 1;
-          const int tile = min(kVTile, sz - ti * kVTile);
-#pragma unroll
-          for (int i = 0; i < kVPer; ++i) {
-            const int t = i * kBlock + tid;
-            if (t < tile) {
-              const float4 nn = rn[i];
-              const float tx = nn.x - m0, ty = nn.y - m1;
-              const bool side = (ax * tx + ay * ty > 0.f);
-              const float nz = fabsf(nn.z);
-              s_v[buf][0][t] = side ? nn.x : 0.f;
-              s_v[buf][1][t] = side ? nn.y : 0.f;
-              s_v[buf][2][t] = side ? nz : 0.f;
-              s_v[buf][3][t] = side ? 0.f : nn.x;
-              s_v[buf][4][t] = side ? 0.f : nn.y;
-              s_v[buf][5][t] = side ? 0.f : nz;
-              na += side ? 1u : 0u;
-            }
-          }
-          __syncthreads();
-          if (ti + 1 < n_tiles) fetch(ti + 1);
-          if (chain_wave && lane < 6) pacc = chain_sum(s_v[buf][lane], tile, pacc);
-        }
-      }
-#pragma unroll
-      for (int off = kWave / 2; off > 0; off >>= 1) na += (unsigned)__shfl_xor((int)na, off);
+      const float pacc =
+          verify_pass<false>(m, sz, fit_pt, fit_nrm, s_v, 6, [&](const float4&, const float4& nn, float* slot) {
+            const float tx = nn.x - m0, ty = nn.y - m1;
+            const bool side = (ax * tx + ay * ty > 0.f);
+            const float nz = fabsf(nn.z);
+            slot[0 * kVStride] = side ? nn.x : 0.f;
+            slot[1 * kVStride] = side ? nn.y : 0.f;
+            slot[2 * kVStride] = side ? nz : 0.f;
+            slot[3 * kVStride] = side ? 0.f : nn.x;
+            slot[4 * kVStride] = side ? 0.f : nn.y;
+            slot[5 * kVStride] = side ? 0.f : nz;
+            na += side ? 1u : 0u;
+          });
+      na = block_sum_u32(na, s_cnt);
       __syncthreads();
-      if (lane == 0) s_cnt[tid / kWave] = na;
       if (chain_wave && lane < 6) s_bc[lane] = pacc;
       __syncthreads();
-      na = 0;
-      for (int w = 0; w < kBlock / kWave; ++w) na += s_cnt[w];
       const unsigned nb = (unsigned)sz - na;
       if (na != 0 && nb != 0) {
         const float fa = (float)na, fb = (float)nb;
