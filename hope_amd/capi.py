@@ -71,7 +71,8 @@ ABI_SYMBOLS = [
     "set_height_window", "segment_depth_u16", "segment_cloud_xyz", "num_frames",
     "frame_counts", "get_transformed", "get_downsampled", "get_normals", "get_fit_indices",
     "get_knn", "get_labels", "get_clusters", "get_cluster_indices", "get_max_plane",
-    "last_timing",
+    "last_timing", "grid_from_bbox", "shard_bbox", "shard_z_histogram", "shard_route",
+    "downsample_cloud_bbox", "segment_downsampled",
 ]
 
 
@@ -113,6 +114,12 @@ class HopeLib:
             "get_cluster_indices": (C.c_int, [vp, i32, i32, vp, i32]),
             "get_max_plane": (C.c_int, [vp, i32, C.POINTER(HopeMaxPlane)]),
             "last_timing": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+            "grid_from_bbox": (C.c_int, [vp, vp, vp, vp]),
+            "shard_bbox": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, i32, i32, vp, C.POINTER(C.c_int64)]),
+            "shard_z_histogram": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, i32, i32, vp, vp, i32]),
+            "shard_route": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, i32, i32, vp, vp, i32, i32, vp, i32, vp]),
+            "downsample_cloud_bbox": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, i32, vp]),
+            "segment_downsampled": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, i32, vp, C.c_int64]),
         }
         self.fn = {}
         for name, (res, args) in sig.items():
@@ -228,6 +235,50 @@ class HopeContext:
         return self._check(
             self.lib.fn["segment_cloud_xyz"](self._h, dev_ptr, n, stride_bytes,
                                              1 if apply_filter_transform else 0, 1), "segment_cloud_xyz")
+
+    # -- staged entry points: one cloud across several ranks (hope_amd/sharding.py) ----------
+    # ptr: address of n records of stride_bytes bytes, on the host or (on_device) in HBM
+    def grid_from_bbox(self, bbox):
+        b = np.ascontiguousarray(bbox, dtype=np.float32)
+        mn, dv = np.zeros(3, np.int32), np.zeros(3, np.int32)
+        st = self._check(self.lib.fn["grid_from_bbox"](self._h, b.ctypes.data, mn.ctypes.data, dv.ctypes.data),
+                         "grid_from_bbox")
+        return mn, dv, st
+
+    def shard_bbox(self, ptr, n, stride_bytes, apply_filter_transform, on_device):
+        bbox = np.zeros(6, np.float32)
+        n_raw = C.c_int64(0)
+        self._check(self.lib.fn["shard_bbox"](self._h, ptr, n, stride_bytes, int(apply_filter_transform),
+                                              int(on_device), bbox.ctypes.data, C.byref(n_raw)), "shard_bbox")
+        return bbox, n_raw.value
+
+    def shard_z_histogram(self, ptr, n, stride_bytes, apply_filter_transform, on_device, bbox, n_bins):
+        b = np.ascontiguousarray(bbox, dtype=np.float32)
+        hist = np.zeros(n_bins, np.int64)
+        self._check(self.lib.fn["shard_z_histogram"](self._h, ptr, n, stride_bytes, int(apply_filter_transform),
+                                                     int(on_device), b.ctypes.data, hist.ctypes.data, n_bins),
+                    "shard_z_histogram")
+        return hist
+
+    def shard_route(self, ptr, n, stride_bytes, apply_filter_transform, on_device, bbox, layer_owner, n_ranks,
+                    out_ptr, out_on_device):
+        b = np.ascontiguousarray(bbox, dtype=np.float32)
+        own = np.ascontiguousarray(layer_owner, dtype=np.int32)
+        counts = np.zeros(n_ranks, np.int64)
+        self._check(self.lib.fn["shard_route"](self._h, ptr, n, stride_bytes, int(apply_filter_transform),
+                                               int(on_device), b.ctypes.data, own.ctypes.data, own.shape[0], n_ranks,
+                                               out_ptr, int(out_on_device), counts.ctypes.data), "shard_route")
+        return counts
+
+    def downsample_cloud_bbox(self, ptr, n, stride_bytes, on_device, bbox):
+        b = np.ascontiguousarray(bbox, dtype=np.float32)
+        return self._check(self.lib.fn["downsample_cloud_bbox"](self._h, ptr, n, stride_bytes, int(on_device),
+                                                                b.ctypes.data), "downsample_cloud_bbox")
+
+    def segment_downsampled(self, ptr, n_vox, stride_bytes, on_device, bbox, n_raw_total):
+        b = np.ascontiguousarray(bbox, dtype=np.float32)
+        return self._check(self.lib.fn["segment_downsampled"](self._h, ptr, n_vox, stride_bytes, int(on_device),
+                                                              b.ctypes.data, int(n_raw_total)), "segment_downsampled")
 
     # -- results -------------------------------------------------------------------------
     def num_frames(self):

@@ -128,6 +128,11 @@ struct hope_ctx {
   std::string err;
   double whole_ms = 0, ref_ms = 0;
   int normals_cap_small = 0;  // test knob: force the neighbour-list overflow path
+  // options of the staged (multi-GPU) entry points, reset after every call
+  const float* forced_bbox = nullptr;  // 6 floats: use this bounding box instead of the input's own
+  int stop_after_voxel = 0;            // A5 only
+  int input_is_downsampled = 0;        // the input already is the VoxelGrid output (A6..A12 only)
+  long long n_raw_override = -1;
   unsigned knn_fine_limit = 4096;  // more left-over k-NN queries than this build the coarse index (test knob)
   unsigned n_knn_todo = 0;
   int force_ieee_div = 0;     // test knob HOPE_DEBUG_IEEE_DIV
@@ -750,6 +755,21 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   return HOPE_OK;
 }
 
+inline int adopt_downsampled(hope_ctx* c, const CloudSrc& src, size_t n, float4*& d_vox, int*& d_vox_frame)
+{
+  ALLOC(d_vox, float4, n);
+  ALLOC(d_vox_frame, int, n);
+  hipLaunchKernelGGL((k_adopt_downsampled<CloudSrc>), dim3(nblk(n)), dim3(kBlock), 0, c->stream, src, c->d_fi, d_vox,
+                     d_vox_frame);
+  c->n_vox_total = (unsigned)n;
+  return HOPE_OK;
+}
+inline int adopt_downsampled(hope_ctx* c, const DepthSrc&, size_t, float4*&, int*&)
+{
+  c->err = "a depth frame cannot be an already down-sampled cloud";
+  return HOPE_E_INVALID;
+}
+
 // Decides once per camera model whether the 3-instruction division by a constant reproduces the
 // IEEE quotient on every dividend A1 can produce (k_verify_fast_div); the result is cached.
 int check_fast_div(hope_ctx* c, const DepthSrc& src)
@@ -818,6 +838,10 @@ int run_pipeline(hope_ctx* c, const Src& src, size_t n_per_frame)
     if (st != HOPE_OK) return st;
     prof_close(c, ST_BBOX, pm, src_point_bytes(src) * n_per_frame * F);
   }
+  if (c->forced_bbox) {
+    const float* b = c->forced_bbox;
+    hipLaunchKernelGGL(k_force_bbox, dim3(1), dim3(1), 0, s, d_fi, b[0], b[1], b[2], b[3], b[4], b[5]);
+  }
   {
     size_t pm = prof_mark(c);
     hipLaunchKernelGGL(k_frame_grid, dim3(1), dim3(1024), 0, s, d_fi, F, c->inv_xy, c->inv_z, c->d_glob);
@@ -840,7 +864,10 @@ int run_pipeline(hope_ctx* c, const Src& src, size_t n_per_frame)
   const int total_bits = cell_bits + bits_for((unsigned long long)F);
   float4* d_vox = nullptr;
   int* d_vox_frame = nullptr;
-  if (n_per_frame > 0) {
+  if (n_per_frame > 0 && c->input_is_downsampled) {
+    st = adopt_downsampled(c, src, n_per_frame, d_vox, d_vox_frame);
+    if (st != HOPE_OK) return st;
+  } else if (n_per_frame > 0) {
     if (total_bits <= 32)
       st = stage_voxel<Src, uint32_t>(c, src, n_per_frame, cell_bits, total_bits, d_vox, d_vox_frame);
     else
@@ -851,7 +878,7 @@ int run_pipeline(hope_ctx* c, const Src& src, size_t n_per_frame)
 
   // ---- A6..A12 ------------------------------------------------------------------------
   bool timed = false;
-  if (c->n_vox_total > 0) {
+  if (c->n_vox_total > 0 && !c->stop_after_voxel) {
     const int zbits = bits_for(c->h_glob->max_div_z - 1);
     const int key2_bits = zbits + bits_for(c->h_glob->total_cols);
     if (key2_bits <= 32)
@@ -868,6 +895,7 @@ int run_pipeline(hope_ctx* c, const Src& src, size_t n_per_frame)
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, c->ev_a, c->ev_b) == hipSuccess) c->ref_ms = ms;
   }
+  if (c->n_raw_override >= 0) c->h_fi[0].n_raw = (int)c->n_raw_override;
   if (c->n_vox_total == 0)
     for (FrameInfo& fi : c->h_fi) fi.n_vox = fi.n_fit = fi.n_segments = fi.n_clusters = 0;
   else if (c->n_fit_total == 0)
@@ -875,7 +903,7 @@ int run_pipeline(hope_ctx* c, const Src& src, size_t n_per_frame)
   rt_post(c);
   int worst = HOPE_OK;
   for (FrameInfo& fi : c->h_fi) {
-    fi.status = fi.n_vox == 0 ? HOPE_EMPTY : (fi.n_fit == 0 ? HOPE_NO_NORMAL_FIT : HOPE_OK);
+    fi.status = fi.n_vox == 0 ? HOPE_EMPTY : ((fi.n_fit == 0 && !c->stop_after_voxel) ? HOPE_NO_NORMAL_FIT : HOPE_OK);
     worst = std::max(worst, fi.status);
   }
   c->whole_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1065,6 +1093,214 @@ HOPE_API int hope_segment_cloud_xyz(hope_ctx* c, const void* xyz, size_t n, size
   const int st = run_pipeline(c, src, n);
   c->frame_poses.swap(saved);
   return st;
+}
+
+/* ---- one cloud across several GPUs ------------------------------------------------------------ */
+namespace {
+
+// device-resident view of a caller's cloud (copied up when it lives on the host)
+int make_cloud_src(hope_ctx* c, const void* xyz, size_t n, size_t stride, int apply, int on_device, CloudSrc& src)
+{
+  if ((!xyz && n > 0) || stride < 12 || (stride % 4) != 0 || n >= 0xffffffffull) {
+    c->err = "bad cloud argument";
+    return HOPE_E_INVALID;
+  }
+  HIPCHK(hipSetDevice(c->cfg.device));
+  const void* d_xyz = xyz;
+  if (!on_device && n > 0) {
+    char* buf;
+    ALLOC(buf, char, n * stride);
+    HIPCHK(hipMemcpyAsync(buf, xyz, n * stride, hipMemcpyHostToDevice, c->stream));
+    d_xyz = buf;
+  }
+  src.base = static_cast<const char*>(d_xyz);
+  src.stride = stride;
+  src.n = (unsigned)n;
+  src.apply = apply ? 1 : 0;
+  src.min_d = c->cfg.min_depth;
+  src.max_d = c->cfg.max_depth;
+  return HOPE_OK;
+}
+
+// FrameInfo[1] with the pose and either an empty or a forced bounding box; grid derived on device
+int shard_frame(hope_ctx* c, const float* bbox)
+{
+  c->n_frames = 1;
+  c->h_fi.assign(1, FrameInfo{});
+  FrameInfo& fi = c->h_fi[0];
+  make_affine(c->pose, fi.aff);
+  for (int d = 0; d < 3; ++d) {
+    fi.bb_min[d] = 0xffffffffu;
+    fi.bb_max[d] = 0u;
+  }
+  FrameInfo* d_fi;
+  ALLOC(d_fi, FrameInfo, 1);
+  c->d_fi = d_fi;
+  HIPCHK(hipMemcpyAsync(d_fi, c->h_fi.data(), sizeof(FrameInfo), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemsetAsync(c->d_glob, 0, sizeof(Globals), c->stream));
+  if (bbox) {
+    hipLaunchKernelGGL(k_force_bbox, dim3(1), dim3(1), 0, c->stream, d_fi, bbox[0], bbox[1], bbox[2], bbox[3], bbox[4],
+                       bbox[5]);
+    // k_frame_grid only builds a grid for a frame with points
+    const int one = 1;
+    HIPCHK(hipMemcpyAsync(&d_fi->n_raw, &one, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_frame_grid, dim3(1), dim3(1024), 0, c->stream, d_fi, 1, c->inv_xy, c->inv_z, c->d_glob);
+  }
+  return HOPE_OK;
+}
+
+}  // namespace
+
+HOPE_API int hope_grid_from_bbox(hope_ctx* c, const float bbox[6], int32_t min_b[3], int32_t div_b[3])
+{
+  if (!c || !bbox || !min_b || !div_b) return HOPE_E_INVALID;
+  // VoxelGrid::applyFilter (PCL 1.8.1 voxel_grid.hpp): the arithmetic of k_frame_grid on the host
+  const float inv[3] = {c->inv_xy, c->inv_xy, c->inv_z};
+  long long dxyz = 1;
+  for (int d = 0; d < 3; ++d) {
+    dxyz *= (long long)((bbox[3 + d] - bbox[d]) * inv[d]) + 1;
+    min_b[d] = (int)std::floor(bbox[d] * inv[d]);
+    div_b[d] = (int)std::floor(bbox[3 + d] * inv[d]) - min_b[d] + 1;
+  }
+  return dxyz > 2147483647LL ? HOPE_E_RANGE : HOPE_OK;
+}
+
+HOPE_API int hope_shard_bbox(hope_ctx* c, const void* xyz, size_t n, size_t stride, int apply, int on_device,
+                             float bbox[6], int64_t* n_raw)
+{
+  if (!c || !bbox || !n_raw) return HOPE_E_INVALID;
+  c->arena.reset();
+  CloudSrc src;
+  int st = make_cloud_src(c, xyz, n, stride, apply, on_device, src);
+  if (st != HOPE_OK) return st;
+  st = shard_frame(c, nullptr);
+  if (st != HOPE_OK) return st;
+  if (n > 0) launch_bbox(c, src, n);
+  HIPCHK(hipMemcpyAsync(c->h_fi.data(), c->d_fi, sizeof(FrameInfo), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const FrameInfo& fi = c->h_fi[0];
+  *n_raw = fi.n_raw;
+  auto ord2f_host = [](unsigned u) {
+    const unsigned v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    float f;
+    std::memcpy(&f, &v, 4);
+    return f;
+  };
+  for (int d = 0; d < 3; ++d) {
+    bbox[d] = fi.n_raw > 0 ? ord2f_host(fi.bb_min[d]) : INFINITY;
+    bbox[3 + d] = fi.n_raw > 0 ? ord2f_host(fi.bb_max[d]) : -INFINITY;
+  }
+  return HOPE_OK;
+}
+
+HOPE_API int hope_shard_z_histogram(hope_ctx* c, const void* xyz, size_t n, size_t stride, int apply, int on_device,
+                                    const float bbox[6], int64_t* hist, int n_bins)
+{
+  if (!c || !bbox || !hist || n_bins <= 0) return HOPE_E_INVALID;
+  c->arena.reset();
+  CloudSrc src;
+  int st = make_cloud_src(c, xyz, n, stride, apply, on_device, src);
+  if (st != HOPE_OK) return st;
+  st = shard_frame(c, bbox);
+  if (st != HOPE_OK) return st;
+  unsigned long long* d_hist;
+  ALLOC(d_hist, unsigned long long, n_bins);
+  HIPCHK(hipMemsetAsync(d_hist, 0, sizeof(unsigned long long) * n_bins, c->stream));
+  if (n > 0) {
+    const unsigned bx = std::max(1u, std::min<unsigned>(nblk(n, kBlock * 16), 2048u));
+    hipLaunchKernelGGL((k_z_histogram<CloudSrc>), dim3(bx), dim3(kBlock), 0, c->stream, src, c->d_fi, c->inv_z, n_bins,
+                       d_hist);
+  }
+  HIPCHK(hipMemcpyAsync(hist, d_hist, sizeof(int64_t) * n_bins, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return HOPE_OK;
+}
+
+HOPE_API int hope_shard_route(hope_ctx* c, const void* xyz, size_t n, size_t stride, int apply, int on_device,
+                              const float bbox[6], const int32_t* layer_owner, int n_bins, int n_ranks, float* out_xyz,
+                              int out_on_device, int64_t* counts)
+{
+  if (!c || !bbox || !layer_owner || n_bins <= 0 || n_ranks <= 0 || !counts) return HOPE_E_INVALID;
+  c->arena.reset();
+  CloudSrc src;
+  int st = make_cloud_src(c, xyz, n, stride, apply, on_device, src);
+  if (st != HOPE_OK) return st;
+  st = shard_frame(c, bbox);
+  if (st != HOPE_OK) return st;
+  for (int r = 0; r < n_ranks; ++r) counts[r] = 0;
+  if (n == 0) return HOPE_OK;
+  PrimAlloc pa{arena_alloc_cb, &c->arena};
+  int* d_owner;
+  uint32_t *k_in, *k_out, *v_in, *v_out;
+  unsigned long long* d_counts;
+  float* d_out;
+  ALLOC(d_owner, int, n_bins);
+  ALLOC(k_in, uint32_t, n);
+  ALLOC(k_out, uint32_t, n);
+  ALLOC(v_in, uint32_t, n);
+  ALLOC(v_out, uint32_t, n);
+  ALLOC(d_counts, unsigned long long, n_ranks + 2);
+  HIPCHK(hipMemcpyAsync(d_owner, layer_owner, sizeof(int) * n_bins, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL((k_route_keys<CloudSrc>), dim3(nblk(n)), dim3(kBlock), 0, c->stream, src, c->d_fi, c->inv_z,
+                     d_owner, n_bins, n_ranks, k_in, v_in);
+  HIPCHK(sort_pairs_u32(pa, k_in, k_out, v_in, v_out, n, bits_for((unsigned long long)n_ranks), c->stream));
+  hipLaunchKernelGGL(k_route_counts, dim3(1), dim3(64), 0, c->stream, k_out, (unsigned)n, n_ranks, d_counts);
+  if (out_on_device) {
+    d_out = out_xyz;
+  } else {
+    ALLOC(d_out, float, 3 * n);
+  }
+  hipLaunchKernelGGL((k_route_export<CloudSrc>), dim3(nblk(n)), dim3(kBlock), 0, c->stream, src, c->d_fi, k_out, v_out,
+                     n_ranks, d_out);
+  std::vector<unsigned long long> h_counts(n_ranks + 1);
+  HIPCHK(hipMemcpyAsync(h_counts.data(), d_counts, sizeof(unsigned long long) * (n_ranks + 1), hipMemcpyDeviceToHost,
+                        c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int r = 0; r < n_ranks; ++r) counts[r] = (int64_t)(h_counts[r + 1] - h_counts[r]);
+  if (!out_on_device && h_counts[n_ranks] > 0) {
+    HIPCHK(hipMemcpyAsync(out_xyz, d_out, sizeof(float) * 3 * h_counts[n_ranks], hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  return HOPE_OK;
+}
+
+static int run_cloud_staged(hope_ctx* c, const void* xyz, size_t n, size_t stride, int on_device, const float bbox[6],
+                            int stop_after_voxel, int is_downsampled, long long n_raw_override)
+{
+  c->arena.reset();
+  c->n_frames = 1;
+  c->src_kind = 2;
+  CloudSrc src;
+  int st = make_cloud_src(c, xyz, n, stride, 0, on_device, src);
+  if (st != HOPE_OK) return st;
+  std::vector<Pose> saved;
+  saved.swap(c->frame_poses);
+  c->csrc = src;
+  c->forced_bbox = bbox;
+  c->stop_after_voxel = stop_after_voxel;
+  c->input_is_downsampled = is_downsampled;
+  c->n_raw_override = n_raw_override;
+  st = run_pipeline(c, src, n);
+  c->forced_bbox = nullptr;
+  c->stop_after_voxel = 0;
+  c->input_is_downsampled = 0;
+  c->n_raw_override = -1;
+  c->frame_poses.swap(saved);
+  return st;
+}
+
+HOPE_API int hope_downsample_cloud_bbox(hope_ctx* c, const void* xyz, size_t n, size_t stride, int on_device,
+                                        const float bbox[6])
+{
+  if (!c || !bbox) return HOPE_E_INVALID;
+  return run_cloud_staged(c, xyz, n, stride, on_device, bbox, 1, 0, -1);
+}
+
+HOPE_API int hope_segment_downsampled(hope_ctx* c, const void* vox, size_t n_vox, size_t stride, int on_device,
+                                      const float bbox[6], int64_t n_raw_total)
+{
+  if (!c || !bbox) return HOPE_E_INVALID;
+  return run_cloud_staged(c, vox, n_vox, stride, on_device, bbox, 0, 1, (long long)n_raw_total);
 }
 
 #define GET_FRAME(c, frame)                                   \

@@ -1799,6 +1799,114 @@ k_cluster_verify_b(const uint32_t* members, const uint32_t* cl_first, const floa
   }
 }
 
+// ---- one cloud across several GPUs (hope_shard_*) ------------------------
+// The global bounding box (all-reduced by the caller) replaces the local one, so that every rank
+// derives the same VoxelGrid min_b / div_b.
+__global__ void k_force_bbox(FrameInfo* fi, float mnx, float mny, float mnz, float mxx, float mxy, float mxz)
+{
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  fi[0].bb_min[0] = f2ord(mnx);
+  fi[0].bb_min[1] = f2ord(mny);
+  fi[0].bb_min[2] = f2ord(mnz);
+  fi[0].bb_max[0] = f2ord(mxx);
+  fi[0].bb_max[1] = f2ord(mxy);
+  fi[0].bb_max[2] = f2ord(mxz);
+}
+
+// z-layer histogram of the surviving points: layer = VoxelGrid's k index.  Votes go to LDS-private
+// bins of the workgroup (one ds_add per point; layers of a horizontal surface repeat within a
+// wave, which the LDS atomic unit serialises cheaply) and are merged into the 64-bit global bins
+// once per workgroup.  More layers than the LDS table holds: straight to the global bins.
+constexpr int kHistLds = 8192;
+
+template <class Src>
+__global__ void __launch_bounds__(kBlock)
+k_z_histogram(Src src, const FrameInfo* fi, float inv_z, int n_bins, unsigned long long* hist)
+{
+  __shared__ unsigned s_bins[kHistLds];
+  const bool lds = n_bins <= kHistLds;
+  if (lds)
+    for (int b = threadIdx.x; b < n_bins; b += kBlock) s_bins[b] = 0u;
+  __syncthreads();
+  const unsigned n = src_count(src);
+  const float mbz = (float)fi[0].min_b[2];
+  for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    float x, y, z;
+    if (!load_point(src, fi, 0, i, x, y, z)) continue;
+    const int k = (int)(floorf(z * inv_z) - mbz);
+    if (k < 0 || k >= n_bins) continue;
+    if (lds) atomicAdd(&s_bins[k], 1u); else atomicAdd(&hist[k], 1ull);
+  }
+  __syncthreads();
+  if (lds)
+    for (int b = threadIdx.x; b < n_bins; b += kBlock)
+      if (s_bins[b]) atomicAdd(&hist[b], (unsigned long long)s_bins[b]);
+}
+
+// destination rank of every point = owner of its z layer (points that do not survive A2: n_ranks)
+template <class Src>
+__global__ void __launch_bounds__(kBlock)
+k_route_keys(Src src, const FrameInfo* fi, float inv_z, const int* layer_owner, int n_bins, int n_ranks,
+             uint32_t* keys, uint32_t* vals)
+{
+  const unsigned n = src_count(src);
+  const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  float x, y, z;
+  uint32_t key = (uint32_t)n_ranks;
+  if (load_point(src, fi, 0, i, x, y, z)) {
+    const int k = (int)(floorf(z * inv_z) - (float)fi[0].min_b[2]);
+    if (k >= 0 && k < n_bins) key = (uint32_t)layer_owner[k];
+  }
+  keys[i] = key;
+  vals[i] = i;
+}
+
+// transformed points in routed order (destination major, source index ascending) + per-rank counts
+template <class Src>
+__global__ void __launch_bounds__(kBlock)
+k_route_export(Src src, const FrameInfo* fi, const uint32_t* skeys, const uint32_t* svals, int n_ranks, float* out)
+{
+  const unsigned n = src_count(src);
+  const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n || skeys[i] >= (uint32_t)n_ranks) return;
+  float x = 0.f, y = 0.f, z = 0.f;
+  load_point(src, fi, 0, svals[i], x, y, z);
+  out[3 * (size_t)i] = x;
+  out[3 * (size_t)i + 1] = y;
+  out[3 * (size_t)i + 2] = z;
+}
+
+__global__ void k_route_counts(const uint32_t* skeys, unsigned n, int n_ranks, unsigned long long* counts)
+{
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > n_ranks) return;
+  unsigned lo = 0, hi = n;
+  while (lo < hi) {  // first position with key >= r
+    const unsigned mid = (lo + hi) >> 1;
+    if (skeys[mid] < (uint32_t)r) lo = mid + 1; else hi = mid;
+  }
+  counts[r] = lo;  // prefix: counts[r+1] - counts[r] points go to rank r
+}
+
+// an already down-sampled cloud (VoxelGrid order) becomes the voxel stage's output as it is
+template <class Src>
+__global__ void __launch_bounds__(kBlock)
+k_adopt_downsampled(Src src, FrameInfo* fi, float4* vox, int* vox_frame)
+{
+  const unsigned n = src_count(src);
+  const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+  if (i == 0) {
+    fi[0].vox_start = 0;
+    fi[0].n_vox = (int)n;
+  }
+  if (i >= n) return;
+  float x = 0.f, y = 0.f, z = 0.f;
+  load_point(src, fi, 0, i, x, y, z);
+  vox[i] = make_float4(x, y, z, 0.f);
+  vox_frame[i] = 0;
+}
+
 // ---- on-demand export of the transformed cloud (hope_get_transformed) -------------------
 template <class Src>
 __global__ void __launch_bounds__(kBlock)

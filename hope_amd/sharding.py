@@ -1,7 +1,15 @@
 """Multi-GPU use of the path: frames are independent extraction problems, so a batch is sharded
 by contiguous frame range (one process per GPU) and only the small plane records are gathered on
 rank 0.  There is no data-path collective ("Frames: yes, trivially").
-A single huge cloud (configs 3/4) is not sharded yet: see DESIGN.md "Multi-GPU"."""
+
+
+A single large cloud (configs 3/4) is sharded by contiguous point range; the raw-point work
+(A2, A3, bounding box, z-layer histogram, VoxelGrid) runs on every rank's share and the three
+exchanges the path really needs sit between the stages: a MIN/MAX all-reduce of the bounding box
+(6 floats), a SUM all-reduce of the int64 z-layer histogram (a few hundred bins), one all-to-all
+that sends every surviving point to the rank owning its z band, and one all-gather of the
+down-sampled cloud (~N_raw/10..40 points).  A6..A12 then run on the gathered down-sampled cloud;
+see segment_cloud_sharded.  Every step is bit-identical to the single-process path."""
 import numpy as np
 
 
@@ -45,3 +53,84 @@ def records_equal(a, b):
     return (a["frame"] == b["frame"] and a["n_raw"] == b["n_raw"] and a["n_vox"] == b["n_vox"] and
             a["n_fit"] == b["n_fit"] and a["n_planes"] == b["n_planes"] and
             np.asarray(a["clusters"]).tobytes() == np.asarray(b["clusters"]).tobytes())
+
+
+# ---- one cloud across several ranks --------------------------------------------------------------
+def band_partition(hist, world):
+    """Owner rank of every z layer: contiguous bands holding about equal numbers of points
+    (hist: all-reduced survivors per layer).  Deterministic, so every rank derives the same map."""
+    hist = np.asarray(hist, dtype=np.int64)
+    total = int(hist.sum())
+    owner = np.zeros(hist.shape[0], np.int32)
+    if total == 0 or world == 1:
+        return owner
+    before = np.cumsum(hist) - hist          # points in the layers below
+    owner[:] = np.minimum((before * world) // total, world - 1).astype(np.int32)
+    return owner
+
+
+def _ptr(t):
+    return t.data_ptr(), t.is_cuda
+
+
+def segment_cloud_sharded(ctx, xyz_local, dist, apply_filter_transform=False):
+    """xyz_local: this rank's contiguous share of the cloud, float32 torch tensor [n, 3] (CPU with
+    gloo, cuda with nccl = RCCL).  Ranks hold the points in rank order (rank 0 the lowest indices).
+    Afterwards `ctx` of EVERY rank holds the result of the whole cloud (A6..A12 run replicated on
+    the gathered down-sampled cloud), exactly as if one process had called segment_cloud on it.
+    Returns a dict of the exchanged sizes."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    xyz_local = xyz_local.contiguous()
+    dev = xyz_local.device
+    n = xyz_local.shape[0]
+    ptr, on_dev = _ptr(xyz_local)
+    # 1. bounding box (MIN/MAX as one MAX over [-min, max]) and survivor count
+    bbox, n_raw = ctx.shard_bbox(ptr, n, 12, apply_filter_transform, on_dev)
+    mm = torch.tensor(np.concatenate([-bbox[:3], bbox[3:]]), dtype=torch.float32, device=dev)
+    cnt = torch.tensor([n_raw], dtype=torch.int64, device=dev)
+    dist.all_reduce(mm, op=dist.ReduceOp.MAX)
+    dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    n_raw_total = int(cnt.item())
+    mmh = mm.cpu().numpy()
+    gbbox = np.concatenate([-mmh[:3], mmh[3:]]).astype(np.float32)
+    if n_raw_total == 0:
+        ctx.segment_cloud(np.zeros((0, 3), np.float32))
+        return {"n_raw_total": 0, "n_vox": 0, "sent": [0] * world, "received": [0] * world}
+    _, div_b, st = ctx.grid_from_bbox(gbbox)
+    n_bins = int(div_b[2])
+    # 2. z-layer histogram -> bands
+    hist = torch.from_numpy(ctx.shard_z_histogram(ptr, n, 12, apply_filter_transform, on_dev, gbbox, n_bins)).to(dev)
+    dist.all_reduce(hist, op=dist.ReduceOp.SUM)
+    owner = band_partition(hist.cpu().numpy(), world)
+    # 3. route the survivors to their band owners
+    routed = torch.empty((max(n_raw, 1), 3), dtype=torch.float32, device=dev)
+    counts = ctx.shard_route(ptr, n, 12, apply_filter_transform, on_dev, gbbox, owner, world, routed.data_ptr(),
+                             routed.is_cuda)
+    send = torch.tensor(counts, dtype=torch.int64, device=dev)
+    recv = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(recv, send)
+    recv_l, send_l = [int(v) for v in recv.cpu().tolist()], [int(v) for v in counts]
+    mine = torch.empty((max(sum(recv_l), 1), 3), dtype=torch.float32, device=dev)
+    dist.all_to_all_single(mine[:sum(recv_l)].view(-1), routed[:n_raw].view(-1), [3 * v for v in recv_l],
+                           [3 * v for v in send_l])
+    # 4. VoxelGrid on the band with the global grid; gather the down-sampled cloud
+    ctx.downsample_cloud_bbox(mine.data_ptr(), sum(recv_l), 12, mine.is_cuda, gbbox)
+    vox_local = torch.from_numpy(ctx.downsampled(0)).to(dev)
+    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+    sizes[rank] = vox_local.shape[0]
+    dist.all_reduce(sizes, op=dist.ReduceOp.SUM)
+    sizes_l = [int(v) for v in sizes.cpu().tolist()]
+    pad = max(max(sizes_l), 1)
+    buf = torch.zeros((pad, 3), dtype=torch.float32, device=dev)
+    buf[:vox_local.shape[0]] = vox_local
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    vox_all = torch.cat([p[:s] for p, s in zip(parts, sizes_l)]).contiguous()
+    # 5. A6..A12 on the whole down-sampled cloud
+    if vox_all.shape[0] == 0:
+        ctx.segment_cloud(np.zeros((0, 3), np.float32))
+    else:
+        ctx.segment_downsampled(vox_all.data_ptr(), vox_all.shape[0], 12, vox_all.is_cuda, gbbox, n_raw_total)
+    return {"n_raw_total": n_raw_total, "n_vox": int(vox_all.shape[0]), "sent": send_l, "received": recv_l,
+            "bands": owner}

@@ -170,6 +170,43 @@ HOPE_API int hope_get_max_plane(hope_ctx* ctx, int frame, hope_max_plane* out);
  * window (findAllPlanes only, plane_segment.cpp:157-169) */
 HOPE_API int hope_last_timing(hope_ctx* ctx, double* whole_ms, double* ref_window_ms);
 
+/* ---- one cloud across several GPUs ---------------------------------------------------
+ * No counterpart in the reference (one process, one thread); SURVEY.md section 8e.  One process
+ * per GPU holds a contiguous index range of the raw cloud.  The stages below are the device
+ * work; the exchanges between them (bbox MIN/MAX and int64 z-histogram all-reduce, one
+ * all-to-all of routed points, one all-gather of the down-sampled cloud) are the caller's
+ * (hope_amd/sharding.py: torch.distributed over RCCL).  Results are bit-identical to one
+ * hope_segment_cloud_xyz call on the whole cloud:
+ *   1. hope_shard_bbox          local bounding box + survivor count after A2/A3
+ *   2. hope_grid_from_bbox      VoxelGrid min_b / div_b of the all-reduced box (A5's grid)
+ *   3. hope_shard_z_histogram   survivors per z layer of that grid (all-reduce: SUM)
+ *   4. hope_shard_route         transformed survivors grouped by the rank owning their z layer,
+ *                               source order kept (all-to-all; concatenating the received pieces
+ *                               in rank order keeps ascending global index = VoxelGrid's sum order)
+ *   5. hope_downsample_cloud_bbox  A5 on the received points with the global grid; the band
+ *                               owners' outputs concatenated in rank order are the VoxelGrid
+ *                               output of the whole cloud (hope_get_downsampled; all-gather)
+ *   6. hope_segment_downsampled A6..A12 on the gathered down-sampled cloud                      */
+HOPE_API int hope_grid_from_bbox(hope_ctx* ctx, const float bbox_min_max[6], int32_t min_b[3],
+                                 int32_t div_b[3]);
+HOPE_API int hope_shard_bbox(hope_ctx* ctx, const void* xyz, size_t n, size_t stride_bytes,
+                             int apply_filter_transform, int on_device, float bbox_min_max[6],
+                             int64_t* n_raw);
+HOPE_API int hope_shard_z_histogram(hope_ctx* ctx, const void* xyz, size_t n, size_t stride_bytes,
+                                    int apply_filter_transform, int on_device,
+                                    const float bbox_min_max[6], int64_t* hist, int n_bins);
+/* layer_owner[n_bins]: rank of every z layer; out_xyz: room for n_raw*3 floats; counts[n_ranks] */
+HOPE_API int hope_shard_route(hope_ctx* ctx, const void* xyz, size_t n, size_t stride_bytes,
+                              int apply_filter_transform, int on_device,
+                              const float bbox_min_max[6], const int32_t* layer_owner, int n_bins,
+                              int n_ranks, float* out_xyz, int out_on_device, int64_t* counts);
+HOPE_API int hope_downsample_cloud_bbox(hope_ctx* ctx, const void* xyz, size_t n,
+                                        size_t stride_bytes, int on_device,
+                                        const float bbox_min_max[6]);
+HOPE_API int hope_segment_downsampled(hope_ctx* ctx, const void* vox_xyz, size_t n_vox,
+                                      size_t stride_bytes, int on_device,
+                                      const float bbox_min_max[6], int64_t n_raw_total);
+
 /* ---- instrumentation (HIP library only; no counterpart in the reference) ------------- */
 /* Per-stage device time measured with HIP events on the ctx stream, accumulated over the
  * segment calls made while enabled.  hope_profile_enable also clears the accumulators. */

@@ -87,6 +87,8 @@ struct Frame {
 struct hope_ctx {
   hope_config cfg;
   float th_theta, th_angle, th_norm;
+  const float* forced_bbox = nullptr;  // staged (multi-rank) calls: the all-reduced bounding box
+  int stop_after_voxel = 0, input_is_downsampled = 0;
   Pose pose;
   std::vector<Pose> frame_poses;
   std::vector<Frame> frames;
@@ -179,6 +181,12 @@ void voxel_grid(const hope_ctx* c, Frame& f)
     }
   }
   if (n_finite == 0) return;
+  if (c->forced_bbox) {
+    for (int d = 0; d < 3; ++d) {
+      mn[d] = c->forced_bbox[d];
+      mx[d] = c->forced_bbox[3 + d];
+    }
+  }
   int64_t dxyz[3];
   for (int d = 0; d < 3; ++d) dxyz[d] = static_cast<int64_t>((mx[d] - mn[d]) * inv[d]) + 1;
   if ((dxyz[0] * dxyz[1] * dxyz[2]) > static_cast<int64_t>(std::numeric_limits<int32_t>::max())) {
@@ -726,12 +734,25 @@ void run_frame_after_transform(hope_ctx* c, Frame& f, double& ref_ms)
 {
   f.counts.n_raw = (int64_t)f.tx.size();
   f.counts.status = HOPE_OK;
-  voxel_grid(c, f);
+  if (c->input_is_downsampled) {
+    // the input is VoxelGrid's output already: only the grid is derived (from the forced bbox)
+    const float inv[3] = {1.0f / c->cfg.th_xy, 1.0f / c->cfg.th_xy, 1.0f / c->cfg.th_z};
+    for (int d = 0; d < 3; ++d) {
+      f.counts.min_b[d] = static_cast<int>(std::floor(c->forced_bbox[d] * inv[d]));
+      f.counts.grid[d] = static_cast<int>(std::floor(c->forced_bbox[3 + d] * inv[d])) - f.counts.min_b[d] + 1;
+    }
+    f.vx = f.tx;
+    f.vy = f.ty;
+    f.vz = f.tz;
+  } else {
+    voxel_grid(c, f);
+  }
   f.counts.n_vox = (int64_t)f.vx.size();
   if (f.vx.empty()) {
     f.counts.status = HOPE_EMPTY;
     return;
   }
+  if (c->stop_after_voxel) return;
   KdTree tree;
   const bool use_tree = !c->use_bruteforce;
   if (use_tree) tree.init(f.vx.data(), f.vy.data(), f.vz.data(), (int)f.vx.size());
@@ -1001,6 +1022,133 @@ ORACLE_API int hope_oracle_segment_cloud_xyz(hope_ctx* ctx, const void* xyz, siz
   run_frame_after_transform(ctx, f, ctx->ref_ms);
   ctx->whole_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return worst_status(ctx);
+}
+
+/* ---- staged entry points for one cloud across several ranks (include/hope_gpu.h) ------------ */
+namespace {
+// A2/A3 of one record; false if the point is dropped
+bool cloud_point(const hope_ctx* ctx, const Affine& a, const char* base, size_t stride, size_t i, int apply, float p[3])
+{
+  std::memcpy(p, base + i * stride, 12);
+  if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) return false;
+  if (apply) {
+    if (p[2] < ctx->cfg.min_depth || p[2] > ctx->cfg.max_depth) return false;
+    float ox, oy, oz;
+    apply_affine(a, p[0], p[1], p[2], ox, oy, oz);
+    p[0] = ox;
+    p[1] = oy;
+    p[2] = oz;
+    if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) return false;
+  }
+  return true;
+}
+}  // namespace
+
+ORACLE_API int hope_oracle_grid_from_bbox(hope_ctx* ctx, const float bbox[6], int32_t min_b[3], int32_t div_b[3])
+{
+  if (!ctx || !bbox || !min_b || !div_b) return HOPE_E_INVALID;
+  const float inv[3] = {1.0f / ctx->cfg.th_xy, 1.0f / ctx->cfg.th_xy, 1.0f / ctx->cfg.th_z};
+  int64_t dxyz = 1;
+  for (int d = 0; d < 3; ++d) {
+    dxyz *= static_cast<int64_t>((bbox[3 + d] - bbox[d]) * inv[d]) + 1;
+    min_b[d] = static_cast<int>(std::floor(bbox[d] * inv[d]));
+    div_b[d] = static_cast<int>(std::floor(bbox[3 + d] * inv[d])) - min_b[d] + 1;
+  }
+  return dxyz > static_cast<int64_t>(std::numeric_limits<int32_t>::max()) ? HOPE_E_RANGE : HOPE_OK;
+}
+
+ORACLE_API int hope_oracle_shard_bbox(hope_ctx* ctx, const void* xyz, size_t n, size_t stride, int apply, int,
+                                      float bbox[6], int64_t* n_raw)
+{
+  if (!ctx || !bbox || !n_raw || (!xyz && n > 0)) return HOPE_E_INVALID;
+  const Affine a = make_affine(ctx->pose);
+  for (int d = 0; d < 3; ++d) {
+    bbox[d] = std::numeric_limits<float>::infinity();
+    bbox[3 + d] = -std::numeric_limits<float>::infinity();
+  }
+  int64_t cnt = 0;
+  for (size_t i = 0; i < n; ++i) {
+    float p[3];
+    if (!cloud_point(ctx, a, static_cast<const char*>(xyz), stride, i, apply, p)) continue;
+    ++cnt;
+    for (int d = 0; d < 3; ++d) {
+      bbox[d] = std::min(bbox[d], p[d]);
+      bbox[3 + d] = std::max(bbox[3 + d], p[d]);
+    }
+  }
+  *n_raw = cnt;
+  return HOPE_OK;
+}
+
+ORACLE_API int hope_oracle_shard_z_histogram(hope_ctx* ctx, const void* xyz, size_t n, size_t stride, int apply, int,
+                                             const float bbox[6], int64_t* hist, int n_bins)
+{
+  if (!ctx || !bbox || !hist || n_bins <= 0) return HOPE_E_INVALID;
+  const Affine a = make_affine(ctx->pose);
+  const float inv_z = 1.0f / ctx->cfg.th_z;
+  const int min_bz = static_cast<int>(std::floor(bbox[2] * inv_z));
+  for (int b = 0; b < n_bins; ++b) hist[b] = 0;
+  for (size_t i = 0; i < n; ++i) {
+    float p[3];
+    if (!cloud_point(ctx, a, static_cast<const char*>(xyz), stride, i, apply, p)) continue;
+    const int k = static_cast<int>(std::floor(p[2] * inv_z) - static_cast<float>(min_bz));
+    if (k >= 0 && k < n_bins) hist[k] += 1;
+  }
+  return HOPE_OK;
+}
+
+ORACLE_API int hope_oracle_shard_route(hope_ctx* ctx, const void* xyz, size_t n, size_t stride, int apply, int,
+                                       const float bbox[6], const int32_t* layer_owner, int n_bins, int n_ranks,
+                                       float* out_xyz, int, int64_t* counts)
+{
+  if (!ctx || !bbox || !layer_owner || n_bins <= 0 || n_ranks <= 0 || !counts) return HOPE_E_INVALID;
+  const Affine a = make_affine(ctx->pose);
+  const float inv_z = 1.0f / ctx->cfg.th_z;
+  const int min_bz = static_cast<int>(std::floor(bbox[2] * inv_z));
+  std::vector<std::vector<float>> per(n_ranks);
+  for (size_t i = 0; i < n; ++i) {
+    float p[3];
+    if (!cloud_point(ctx, a, static_cast<const char*>(xyz), stride, i, apply, p)) continue;
+    const int k = static_cast<int>(std::floor(p[2] * inv_z) - static_cast<float>(min_bz));
+    if (k < 0 || k >= n_bins) continue;
+    std::vector<float>& v = per[layer_owner[k]];
+    v.insert(v.end(), p, p + 3);
+  }
+  size_t o = 0;
+  for (int r = 0; r < n_ranks; ++r) {
+    counts[r] = (int64_t)(per[r].size() / 3);
+    if (!per[r].empty()) std::memcpy(out_xyz + o, per[r].data(), per[r].size() * sizeof(float));
+    o += per[r].size();
+  }
+  return HOPE_OK;
+}
+
+static int oracle_cloud_staged(hope_ctx* ctx, const void* xyz, size_t n, size_t stride, const float bbox[6], int stop,
+                               int adopt, int64_t n_raw_total)
+{
+  ctx->forced_bbox = bbox;
+  ctx->stop_after_voxel = stop;
+  ctx->input_is_downsampled = adopt;
+  const int st = hope_oracle_segment_cloud_xyz(ctx, xyz, n, stride, 0, 0);
+  ctx->forced_bbox = nullptr;
+  ctx->stop_after_voxel = 0;
+  ctx->input_is_downsampled = 0;
+  if (st >= 0 && n_raw_total >= 0 && !ctx->frames.empty()) ctx->frames[0].counts.n_raw = n_raw_total;
+  return st;
+}
+
+ORACLE_API int hope_oracle_downsample_cloud_bbox(hope_ctx* ctx, const void* xyz, size_t n, size_t stride, int,
+                                                 const float bbox[6])
+{
+  if (!ctx || !bbox) return HOPE_E_INVALID;
+  return oracle_cloud_staged(ctx, xyz, n, stride, bbox, 1, 0, -1);
+}
+
+ORACLE_API int hope_oracle_segment_downsampled(hope_ctx* ctx, const void* vox, size_t n_vox, size_t stride, int,
+                                               const float bbox[6], int64_t n_raw_total)
+{
+  if (!ctx || !bbox) return HOPE_E_INVALID;
+  return oracle_cloud_staged(ctx, vox, n_vox, stride, bbox, 0, 1, n_raw_total);
 }
 
 #define GET_FRAME(ctx, frame)                                            \

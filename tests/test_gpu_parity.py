@@ -220,6 +220,59 @@ def test_knn_leftovers_through_the_coarse_index(hip_lib, oracle_lib, monkeypatch
     assert_frame_equal(o, g_fine, 0)
 
 
+def test_staged_cloud_entry_points(hip_lib, oracle_lib):
+    """The device stages behind hope_amd.sharding.segment_cloud_sharded, driven here for three
+    'ranks' one after the other in one process (the exchanges become numpy concatenations): the
+    result must be the oracle's single-call result, bit for bit, and every stage must agree with the
+    oracle's own staged entry points."""
+    from hope_amd import synth
+    from hope_amd.sharding import band_partition, frame_partition
+    xyz = synth.make_multilevel_cloud(200000, first_index=99, device="cpu").numpy()
+    xyz = (xyz * np.float32(0.25) + np.array([0, 0, 0.2], np.float32)).astype(np.float32)
+    xyz[::1501, 0] = np.nan
+    t = np.array([0.1, -0.2, 0.3], np.float32)
+    q = np.array([0.02, -0.01, 0.38, 0.92], np.float32)
+    world = 3
+    g, o = both(hip_lib, oracle_lib)
+    ref = HopeContext(oracle_lib)
+    for c in (g, o, ref):
+        c.set_pose(t, q)
+    ref.segment_cloud(xyz, apply_filter_transform=True)
+    for c in (g, o):
+        shards = [np.ascontiguousarray(xyz[slice(*frame_partition(xyz.shape[0], world, r))]) for r in range(world)]
+        boxes = [c.shard_bbox(s.ctypes.data, s.shape[0], 12, True, False) for s in shards]
+        gb = np.concatenate([np.min([b[0][:3] for b in boxes], 0), np.max([b[0][3:] for b in boxes], 0)])
+        n_raw = sum(b[1] for b in boxes)
+        assert n_raw == ref.counts(0).n_raw
+        mn, dv, _ = c.grid_from_bbox(gb)
+        assert list(dv) == list(ref.counts(0).grid) and list(mn) == list(ref.counts(0).min_b)
+        hist = sum(c.shard_z_histogram(s.ctypes.data, s.shape[0], 12, True, False, gb, int(dv[2])) for s in shards)
+        assert hist.sum() == n_raw
+        owner = band_partition(hist, world)
+        routed, counts = [], []
+        for s, b in zip(shards, boxes):
+            out = np.zeros((max(b[1], 1), 3), np.float32)
+            counts.append(c.shard_route(s.ctypes.data, s.shape[0], 12, True, False, gb, owner, world,
+                                        out.ctypes.data, False))
+            routed.append(out)
+        vox = []
+        for r in range(world):
+            pieces = []
+            for src in range(world):
+                off = int(counts[src][:r].sum())
+                pieces.append(routed[src][off:off + int(counts[src][r])])
+            mine = np.ascontiguousarray(np.concatenate(pieces))
+            c.downsample_cloud_bbox(mine.ctypes.data, mine.shape[0], 12, False, gb)
+            vox.append(c.downsampled(0).copy())
+        vox_all = np.ascontiguousarray(np.concatenate(vox))
+        assert vox_all.tobytes() == ref.downsampled(0).tobytes()
+        c.segment_downsampled(vox_all.ctypes.data, vox_all.shape[0], 12, False, gb, n_raw)
+        assert summary(c, 0) == summary(ref, 0)
+    # (n_in differs by construction: the last stage's input is the down-sampled cloud)
+    assert np.array_equal(ref.labels(0), g.labels(0)) and np.array_equal(ref.knn(0), g.knn(0))
+    assert ref.clusters(0).tobytes() == g.clusters(0).tobytes()
+
+
 def test_division_by_camera_constants(hip_lib, oracle_lib, monkeypatch):
     """A1's divisions by depth_scale / fx / fy run as a 3-instruction sequence once the library has
     checked it against the IEEE quotient for every possible dividend; the knob forces IEEE divisions.
