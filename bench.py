@@ -156,7 +156,10 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
+                # recorded per bench step (tools/pmc_traffic.py); reported per launch like `achieved`
                 traffic = json.load(open(tpath)).get(dom["stage"])
+                if traffic is not None:
+                    traffic = traffic / dom["timed_regions_per_step"]
             except Exception:
                 traffic = None
         out = {

@@ -88,12 +88,14 @@ inline unsigned nblk(size_t n, int per = kBlock) { return (unsigned)((n + per - 
 // figures come from here; off by default).
 enum Stage {
   ST_BBOX, ST_GRID, ST_VKEYS, ST_VSORT, ST_VRLE, ST_CENTROID, ST_COLKEYS, ST_COLSORT, ST_COLTABLE, ST_NORMALS,
-  ST_FIT, ST_KNN, ST_LABELS, ST_SEGMENTS, ST_VERIFY, ST_COUNT
+  ST_FIT, ST_KNN, ST_KNN_TODO, ST_LABELS, ST_SEGMENTS, ST_VERIFY, ST_COUNT
 };
 const char* const kStageNames[ST_COUNT] = {
   "k_bbox", "k_frame_grid", "k_voxel_keys", "voxel_sort(rocprim)", "voxel_rle+scan(rocprim)", "k_centroids",
   "k_column_keys", "column_sort(rocprim)", "k_column_table+gather", "k_normals", "fit_gate+compact", "k_knn",
+  "k_knn_todo",
   "labels(union+sweeps)", "segments(scan+sort)", "k_cluster_verify"};
+static_assert(sizeof(kStageNames) / sizeof(kStageNames[0]) == ST_COUNT, "one name per stage");
 
 struct Prof {
   int on = 0;
@@ -652,7 +654,7 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
                            fit_pt, fit_frame, cspt, ccol_first, nullptr, c->d_fi, c->inv_xy, c->inv_z, c->cfg.th_xy,
                            kCoarse, K, knn);
     }
-    prof_close(c, ST_KNN, pm, (16.0 + 4.0 * K) * (double)n_todo);
+    prof_close(c, ST_KNN_TODO, pm, (16.0 + 4.0 * K) * (double)n_todo);
   }
   // ---- A9 region growing as min-rank reachability -----------------------------------
   int *rank, *seed_node, *parent, *L, *root, *label;
