@@ -1,0 +1,193 @@
+// hope_node: the reference's benchmark executable (src/hope_node.cpp) over the MI355X library.
+//   hope_node {TUM_DATASET_FOLDER}                                        TUM list  (all.txt, README.md:62-87)
+//   hope_node {POINT_CLOUD_FILE} {ply|pcd}                                point cloud file (README.md:100)
+//   hope_node {ROLL} {PITCH} {YAW}                                        synthetic object (needs ROS; refused here)
+//   hope_node {PREFIX} {RGB} {DEPTH} {TX} {TY} {TZ} {QX} {QY} {QZ} {QW}   single TUM pair (README.md:51)
+// The argument COUNT picks the mode as upstream documents it (hope_node.cpp:49-62); upstream's 1/2/3-argument
+// branches read argv one slot too far (:118,126-127,132-134), which is not reproduced.  There is no viewer:
+// the planes are printed, and when the environment variable HOPE_NODE_DUMP names a file a JSON record per
+// frame is appended to it (tests read that).
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "formats.hpp"
+#include "plane_segment.hpp"
+
+using namespace hope;
+
+namespace {
+
+void printHelp()
+{
+  std::cout << "hope_node VARIABLES\n"
+               "VARIABLES number could be 1, 2, 3, or 10:\n"
+               "1 VARIABLE, test a sequence on TUM dataset, {TUM_DATASET_FOLDER}\n"
+               "Example: ./hope_node /path/to/TUM/rgbd_dataset_freiburg1_desk\n\n"
+               "2 VARIABLES, test on point cloud file, {POINT_CLOUD_FILE} {TYPE}, TYPE could be ply or pcd\n"
+               "Example: ./hope_node ~/loft.ply ply\n\n"
+               "3 VARIABLES, test with the synthetic object, set the pose of the object with {ROLL} {PITCH} {YAW}\n"
+               "Example: ./hope_node 0 0 0\n\n"
+               "10 VARIABLES, test on single TUM pair, {TUM_DATASET_FOLDER} {RGB_IMG} {DEPTH_IMG} {TX} {TY} {TZ} {QX} {QY} {QZ} {QW}\n"
+               "Example: ./hope_node ~/TUM/rgbd_dataset_freiburg1_desk/ rgb/1305031459.259760.png depth/1305031459.274941.png "
+               "-0.2171 -0.0799 1.3959 -0.8445 -0.0451 0.0954 0.5251"
+            << std::endl;
+}
+
+void report(PlaneSegment& hope, const std::string& name, std::ofstream* dump)
+{
+  const hope_counts& c = hope.last_counts();
+  std::printf("[%s] raw %lld  down-sampled %lld  normal-fit %lld  clusters %d  planes %zu\n", name.c_str(), (long long)c.n_raw,
+              (long long)c.n_vox, (long long)c.n_fit, c.n_clusters, hope.plane_coeff_.size());
+  for (size_t i = 0; i < hope.plane_coeff_.size(); ++i) {
+    const std::vector<float>& f = hope.plane_coeff_[i];
+    std::printf("  plane id %3d  z %.4f  x [%.3f, %.3f]  y [%.3f, %.3f]  points %zu", hope.plane_ids()[i], f[0], f[1], f[3], f[2], f[4],
+                hope.plane_points_[i]->size());
+    if (hope.cal_hull_) std::printf("  hull %zu vertices, area %.4f m^2", hope.plane_hull_[i]->size(), hope.plane_area_[i]);
+    std::printf("\n");
+  }
+  if (dump) {
+    *dump << "{\"frame\": \"" << name << "\", \"n_raw\": " << c.n_raw << ", \"n_vox\": " << c.n_vox << ", \"n_fit\": " << c.n_fit
+          << ", \"n_clusters\": " << c.n_clusters << ", \"status\": " << hope.last_status() << ", \"planes\": [";
+    char buf[256];
+    for (size_t i = 0; i < hope.plane_coeff_.size(); ++i) {
+      const std::vector<float>& f = hope.plane_coeff_[i];
+      std::snprintf(buf, sizeof buf, "%s{\"id\": %d, \"coeff\": [%.9g, %.9g, %.9g, %.9g, %.9g], \"points\": %zu, \"hull\": %zu, \"area\": %.9g}",
+                    i ? ", " : "", hope.plane_ids()[i], f[0], f[1], f[2], f[3], f[4], hope.plane_points_[i]->size(),
+                    hope.cal_hull_ ? hope.plane_hull_[i]->size() : (size_t)0, hope.cal_hull_ ? hope.plane_area_[i] : 0.f);
+      *dump << buf;
+    }
+    *dump << "]}" << std::endl;
+  }
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+  data_type type;
+  std::string path_prefix, path_rgb, path_depth, path_list_all, path_cloud, cloud_type;
+  float roll = 0.f, pitch = 0.f, yaw = 0.f;
+  float tx = 0.f, ty = 0.f, tz = 0.f, qx = 0.f, qy = 0.f, qz = 0.f, qw = 0.f;   // file-scope zeros upstream (hope_node.cpp:47)
+
+  if (argc == 2) {
+    type = TUM_LIST;
+    path_prefix = argv[1];
+    path_list_all = path_prefix + "/all.txt";
+    std::cout << "Using the image list from TUM RGB-D SLAM dataset." << std::endl;
+  } else if (argc == 3) {
+    type = POINT_CLOUD;
+    path_cloud = argv[1];
+    cloud_type = argv[2];
+    std::cout << "Using point cloud file " << path_cloud << std::endl;
+  } else if (argc == 4) {
+    type = SYN;
+    roll = (float)std::atof(argv[1]); pitch = (float)std::atof(argv[2]); yaw = (float)std::atof(argv[3]);
+    std::cout << "Using synthetic object." << std::endl;
+  } else if (argc == 11) {
+    type = TUM_SINGLE;
+    int a = 1;
+    path_prefix = argv[a++];
+    path_rgb = path_prefix + argv[a++];       // plain concatenation, hope_node.cpp:141-142
+    path_depth = path_prefix + argv[a++];
+    tx = (float)std::atof(argv[a++]); ty = (float)std::atof(argv[a++]); tz = (float)std::atof(argv[a++]);
+    qx = (float)std::atof(argv[a++]); qy = (float)std::atof(argv[a++]); qz = (float)std::atof(argv[a++]); qw = (float)std::atof(argv[a++]);
+    std::cout << "Using single pair of rgb and depth image of TUM RGB-D SLAM dataset." << std::endl;
+  } else {
+    printHelp();
+    return -1;
+  }
+
+  const float xy_resolution = 0.05f, z_resolution = 0.02f;   // hope_node.cpp:160-161
+  std::cout << "Using threshold: xy@" << xy_resolution << " z@" << z_resolution << std::endl;
+
+  std::ofstream dump_file;
+  std::ofstream* dump = nullptr;
+  if (const char* d = std::getenv("HOPE_NODE_DUMP")) { dump_file.open(d, std::ios::app); if (dump_file) dump = &dump_file; }
+
+  try {
+    PlaneSegment hope(type, xy_resolution, z_resolution);
+    hope.cal_hull_ = std::getenv("HOPE_NODE_HULL") != nullptr;
+    std::string err;
+
+    if (type == SYN) {
+      hope.setRPY(roll, pitch, yaw);
+      PointCloud::Ptr none(new PointCloud);
+      hope.getHorizontalPlanes(none);          // refuses: the synthetic object arrives over a ROS topic upstream
+      return 2;
+    }
+    if (type == POINT_CLOUD) {
+      PointCloud::Ptr src_cloud(new PointCloud);
+      if (cloud_type == "pcd") {
+        if (!readPcd(path_cloud, *src_cloud, err)) { std::cerr << "Couldn't read pcd file. (" << err << ")" << std::endl; return -1; }
+      } else if (cloud_type == "ply") {
+        if (!readPly(path_cloud, *src_cloud, err)) { std::cerr << "Couldn't read ply file. (" << err << ")" << std::endl; return -1; }
+      } else { std::cerr << "Unrecognized file format." << std::endl; return -1; }
+      hope.setQ(qx, qy, qz, qw);
+      hope.getHorizontalPlanes(src_cloud);
+      if (hope.last_status() < 0) return 1;
+      report(hope, path_cloud, dump);
+      std::printf("[TIMER]: total: %.3f ms (whole call %.3f ms)\n", hope.last_timer_window_ms(), hope.last_ms());
+      return 0;
+    }
+    if (type == TUM_SINGLE) {
+      hope.setQ(qx, qy, qz, qw);
+      hope.setT(tx, ty, tz);
+      Image rgb;
+      if (!readPng(path_rgb, rgb, err)) std::cerr << "warning: rgb image not read (" << err << "); colours only matter to the viewer" << std::endl;
+      std::vector<uint16_t> depth; int w = 0, h = 0;
+      if (!readDepthPng(path_depth, depth, w, h, err)) { std::cerr << err << std::endl; return -1; }
+      hope.getHorizontalPlanes(depth.data(), w, h);
+      if (hope.last_status() < 0) return 1;
+      report(hope, path_depth, dump);
+      std::printf("[TIMER]: total: %.3f ms (whole call %.3f ms)\n", hope.last_timer_window_ms(), hope.last_ms());
+      return 0;
+    }
+    // TUM_LIST
+    std::vector<TumEntry> list;
+    if (!readTumList(path_list_all, list, err)) { std::cout << err << std::endl; return 0; }   // upstream prints and goes on with nothing
+    if (list.empty()) return 0;
+    // phaseInput keeps ONE translation for the whole list, the last line's (the globals tx_ ty_ tz_ are
+    // overwritten per line, hope_node.cpp:88-90, and read after the loop, :231); the quaternion is per frame.
+    const TumEntry& last = list.back();
+    const size_t kBatch = 256;                 // frames per device call; 157 MB of depth
+    std::vector<uint16_t> depth_batch;
+    std::vector<float> t, q;
+    double total_ms = 0;
+    size_t done = 0;
+    for (size_t b0 = 0; b0 < list.size(); b0 += kBatch) {
+      const size_t b1 = std::min(list.size(), b0 + kBatch);
+      int w = 0, h = 0;
+      depth_batch.clear(); t.clear(); q.clear();
+      std::vector<std::string> names;
+      for (size_t i = b0; i < b1; ++i) {
+        std::vector<uint16_t> d; int wi, hi;
+        if (!readDepthPng(path_prefix + "/" + list[i].depth, d, wi, hi, err)) { std::cerr << err << std::endl; continue; }
+        if (w == 0) { w = wi; h = hi; }
+        if (wi != w || hi != h) { std::cerr << list[i].depth << ": image size differs from the batch, skipped" << std::endl; continue; }
+        depth_batch.insert(depth_batch.end(), d.begin(), d.end());
+        t.insert(t.end(), last.t, last.t + 3);
+        q.insert(q.end(), list[i].q, list[i].q + 4);
+        names.push_back(list[i].rgb);
+      }
+      if (names.empty()) continue;
+      hope.getHorizontalPlanesBatch(depth_batch.data(), w, h, (int)names.size(), t.data(), q.data(), [&](int f) {
+        std::cout << "Processing: " << names[f] << std::endl;
+        report(hope, names[f], dump);
+      });
+      if (hope.last_status() < 0) return 1;
+      total_ms += hope.last_ms();
+      done += names.size();
+    }
+    std::printf("[TIMER]: %zu frames, %.3f ms in the library, %.4f ms per frame\n", done, total_ms, done ? total_ms / done : 0.0);
+  } catch (const std::exception& e) {
+    std::cerr << "hope_node: " << e.what() << std::endl;
+    return 1;
+  }
+  return 0;
+}

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, synth_frames
+from conftest import GOLDEN, ROOT, synth_frames
 from parity import assert_frame_equal, summary
 
 from hope_amd.capi import HOPE_MODE_RT, HopeContext
@@ -366,3 +366,43 @@ def test_full_size_batch_properties(hip_lib, oracle_lib):
         o.set_pose(t[f], q[f])
         o.segment_depth(depth[f].cpu().numpy().view(np.uint16))
         assert summary(o, 0) == digests[f]
+
+
+@pytest.mark.gpu
+def test_hope_node_and_rt_adapter_on_the_device(oracle_lib, tum_example, tmp_path):
+    """The C++ host layer linked on libhope_hip.so: `hope_node` (single pair, list mode) and the PlaneSegmentRT
+    driver give the records the oracle gives through the same C ABI."""
+    import json
+    import subprocess
+    from test_host_cpu import check_record, expected_planes, run_node, write_tum_dataset
+    node = os.path.join(ROOT, "hope_amd", "host", "hope_node")
+    rt = os.path.join(ROOT, "tests", "_build", "rt_driver_hip")
+    assert os.path.exists(node) and os.path.exists(rt), "build hope_amd/host and tests/ before the GPU run"
+    depth, t, q = tum_example
+    d = write_tum_dataset(tmp_path, [depth], [t], [q])
+    args = [str(d) + "/", "rgb/0.png", "depth/0.png"] + ["%.4f" % v for v in t] + ["%.4f" % v for v in q]
+    r, recs = run_node(node, args, tmp_path)
+    assert r.returncode == 0, r.stderr
+    k, planes = expected_planes(oracle_lib, depth, np.float32([float("%.4f" % v) for v in t]), np.float32([float("%.4f" % v) for v in q]))
+    check_record(recs[0], k, planes)
+    g = np.load(os.path.join(GOLDEN, "synth_frames_0_2.npz"))
+    d = write_tum_dataset(tmp_path / "list", g["depth"], g["t"], g["q"])
+    r, recs = run_node(node, [d], tmp_path, hull=False)
+    assert r.returncode == 0 and len(recs) == 3, r.stderr
+    for i, rec in enumerate(recs):
+        k, planes = expected_planes(oracle_lib, g["depth"][i], g["t"][2], g["q"][i])
+        check_record(rec, k, planes)
+    # RT adapter: the same driver on the oracle build and on the device build prints the same line
+    z = depth.astype(np.float32) / np.float32(5000.0)
+    cols = (np.arange(640, dtype=np.float32) - np.float32(318.6))[None, :]
+    rows = (np.arange(480, dtype=np.float32) - np.float32(255.3))[:, None]
+    cloud = np.stack([cols * z / np.float32(517.0), rows * z / np.float32(517.0), z], -1).reshape(-1, 3)
+    f = tmp_path / "cloud.f32"
+    cloud.astype(np.float32).tofile(f)
+    rt_oracle = os.path.join(ROOT, "tests", "_build", "rt_driver_oracle")
+    for lo, hi, aggr in ((0.5, 1.5, 1), (-0.2, 0.3, 0)):
+        a = [str(f)] + [repr(float(v)) for v in t] + [repr(float(v)) for v in q] + [str(lo), str(hi), str(aggr)]
+        out = [subprocess.run([b] + a, capture_output=True, text=True, timeout=300) for b in (rt, rt_oracle)]
+        assert out[0].returncode == 0 and out[1].returncode == 0, (out[0].stderr, out[1].stderr)
+        assert json.loads(out[0].stdout.splitlines()[-1]) == json.loads(out[1].stdout.splitlines()[-1])
+        assert json.loads(out[0].stdout.splitlines()[-1])["points"] > 0
