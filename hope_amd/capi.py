@@ -73,6 +73,7 @@ ABI_SYMBOLS = [
     "get_knn", "get_labels", "get_clusters", "get_cluster_indices", "get_max_plane",
     "last_timing", "grid_from_bbox", "shard_bbox", "shard_z_histogram", "shard_route",
     "downsample_cloud_bbox", "segment_downsampled",
+    "clusters_upon_plane", "get_upon_cluster_sizes", "get_upon_cluster",
 ]
 
 
@@ -120,6 +121,9 @@ class HopeLib:
             "shard_route": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, i32, i32, vp, vp, i32, i32, vp, i32, vp]),
             "downsample_cloud_bbox": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, i32, vp]),
             "segment_downsampled": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, i32, vp, C.c_int64]),
+            "clusters_upon_plane": (C.c_int, [vp, i32, vp, i32, C.c_float, i32, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+            "get_upon_cluster_sizes": (C.c_int, [vp, vp, i32]),
+            "get_upon_cluster": (C.c_int, [vp, i32, vp, vp, i32]),
         }
         self.fn = {}
         for name, (res, args) in sig.items():
@@ -349,6 +353,27 @@ class HopeContext:
         m = HopeMaxPlane()
         self._check(self.lib.fn["get_max_plane"](self._h, frame, C.byref(m)), "get_max_plane")
         return m
+
+    def clusters_upon_plane(self, contour_xyz, frame=0, tolerance=0.01, min_size=10, max_size=240000):
+        """Utilities::getClustersUponPlane on the last call's src_mono_cloud_: returns
+        (n_upon, [(xyz[size,3], src_index[size]) per cluster, in the reference's order])."""
+        contour = np.ascontiguousarray(contour_xyz, np.float32).reshape(-1, 3)
+        n_cl, n_upon = C.c_int32(), C.c_int64()
+        self._check(self.lib.fn["clusters_upon_plane"](self._h, frame, contour.ctypes.data_as(C.c_void_p), len(contour),
+                                                       tolerance, min_size, max_size, C.byref(n_cl), C.byref(n_upon)),
+                    "clusters_upon_plane")
+        sizes = np.zeros(max(n_cl.value, 1), np.int32)
+        got = self.lib.fn["get_upon_cluster_sizes"](self._h, sizes.ctypes.data_as(C.c_void_p), n_cl.value)
+        assert got == n_cl.value
+        out = []
+        for k in range(n_cl.value):
+            xyz = np.zeros((int(sizes[k]), 3), np.float32)
+            src = np.zeros(int(sizes[k]), np.int32)
+            r = self.lib.fn["get_upon_cluster"](self._h, k, xyz.ctypes.data_as(C.c_void_p), src.ctypes.data_as(C.c_void_p), len(src))
+            if r < 0:
+                self._check(r, "get_upon_cluster")
+            out.append((xyz, src))
+        return n_upon.value, out
 
     def fast_division_active(self):
         return self.lib.fn["fast_division_active"](self._h)

@@ -15,6 +15,7 @@
 #include "kernels.hpp"
 #include "neighbours.hpp"
 #include "prims.hpp"
+#include "upon_plane.hpp"
 
 using namespace hope;
 
@@ -65,6 +66,16 @@ struct Arena {
     }
     blocks.push_back(nb);
     return nb.p;
+  }
+  std::vector<size_t> mark() const
+  {
+    std::vector<size_t> m;
+    for (const Block& b : blocks) m.push_back(b.used);
+    return m;
+  }
+  void rollback(const std::vector<size_t>& m)  // blocks added since the mark become empty again
+  {
+    for (size_t i = 0; i < blocks.size(); ++i) blocks[i].used = i < m.size() ? m[i] : 0;
   }
   void release()
   {
@@ -165,6 +176,13 @@ struct hope_ctx {
   uint32_t* d_members = nullptr;
   uint32_t* d_cl_first = nullptr;
   unsigned n_vox_total = 0, n_fit_total = 0, n_cl_total = 0;
+  // F1 (hope_clusters_upon_plane): clusters as ranges of d_upon_xyz / d_upon_src, in output order
+  struct UponRange { unsigned first, count; };
+  std::vector<UponRange> upon;
+  float* d_upon_xyz = nullptr;
+  int* d_upon_src = nullptr;
+  std::vector<size_t> upon_mark;   // arena fill levels before the last F1 call (rolled back by the next one)
+  bool upon_mark_valid = false;
 };
 
 namespace {
@@ -1033,6 +1051,8 @@ HOPE_API int hope_segment_depth_u16(hope_ctx* c, const uint16_t* depth, int w, i
   }
   HIPCHK(hipSetDevice(c->cfg.device));
   c->arena.reset();
+  c->upon_mark_valid = false;
+  c->upon.clear();
   c->n_frames = n_frames;
   c->src_kind = 1;
   const size_t ppf = (size_t)w * h;
@@ -1073,6 +1093,8 @@ HOPE_API int hope_segment_cloud_xyz(hope_ctx* c, const void* xyz, size_t n, size
   }
   HIPCHK(hipSetDevice(c->cfg.device));
   c->arena.reset();
+  c->upon_mark_valid = false;
+  c->upon.clear();
   c->n_frames = 1;
   c->src_kind = 2;
   const void* d_xyz = xyz;
@@ -1172,6 +1194,8 @@ HOPE_API int hope_shard_bbox(hope_ctx* c, const void* xyz, size_t n, size_t stri
 {
   if (!c || !bbox || !n_raw) return HOPE_E_INVALID;
   c->arena.reset();
+  c->upon_mark_valid = false;
+  c->upon.clear();
   CloudSrc src;
   int st = make_cloud_src(c, xyz, n, stride, apply, on_device, src);
   if (st != HOPE_OK) return st;
@@ -1200,6 +1224,8 @@ HOPE_API int hope_shard_z_histogram(hope_ctx* c, const void* xyz, size_t n, size
 {
   if (!c || !bbox || !hist || n_bins <= 0) return HOPE_E_INVALID;
   c->arena.reset();
+  c->upon_mark_valid = false;
+  c->upon.clear();
   CloudSrc src;
   int st = make_cloud_src(c, xyz, n, stride, apply, on_device, src);
   if (st != HOPE_OK) return st;
@@ -1224,6 +1250,8 @@ HOPE_API int hope_shard_route(hope_ctx* c, const void* xyz, size_t n, size_t str
 {
   if (!c || !bbox || !layer_owner || n_bins <= 0 || n_ranks <= 0 || !counts) return HOPE_E_INVALID;
   c->arena.reset();
+  c->upon_mark_valid = false;
+  c->upon.clear();
   CloudSrc src;
   int st = make_cloud_src(c, xyz, n, stride, apply, on_device, src);
   if (st != HOPE_OK) return st;
@@ -1270,6 +1298,8 @@ static int run_cloud_staged(hope_ctx* c, const void* xyz, size_t n, size_t strid
                             int stop_after_voxel, int is_downsampled, long long n_raw_override)
 {
   c->arena.reset();
+  c->upon_mark_valid = false;
+  c->upon.clear();
   c->n_frames = 1;
   c->src_kind = 2;
   CloudSrc src;
@@ -1379,6 +1409,168 @@ HOPE_API int hope_get_transformed(hope_ctx* c, int frame, float* xyz, int32_t* s
   int st = copy_out(c, xyz, d_xyz, sizeof(float) * 3 * (size_t)F.n_raw);
   if (st != HOPE_OK) return st;
   return copy_out(c, src_index, d_src, sizeof(int) * (size_t)F.n_raw);
+}
+
+// ---- F1: objects on the winning plane ----------------------------------------------------
+extern "C++" {
+namespace {
+struct SizeRec { unsigned size, run; };
+bool compare_point_clusters(const SizeRec& a, const SizeRec& b) { return a.size < b.size; }  // pcl comparePointClusters
+
+template <class Src>
+int upon_plane(hope_ctx* c, const Src& src, size_t n, int frame, const float2* d_contour, const UponFilter& flt, float tolerance,
+               int min_size, int max_size, int32_t* n_clusters, int64_t* n_upon)
+{
+  hipStream_t s = c->stream;
+  PrimAlloc pa{arena_alloc_cb, &c->arena};
+  uint32_t *flags, *scan;
+  ALLOC(flags, uint32_t, n + 1);
+  ALLOC(scan, uint32_t, n + 1);
+  hipLaunchKernelGGL((k_upon_flags<Src>), dim3(nblk(n + 1)), dim3(kBlock), 0, s, src, c->d_fi, frame, d_contour, flt, flags);
+  HIPCHK(exclusive_scan_u32(pa, flags, scan, n + 1, s));
+  uint32_t n_keep = 0;
+  HIPCHK(hipMemcpyAsync(&n_keep, scan + n, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (n_upon) *n_upon = n_keep;
+  if (n_keep == 0) return HOPE_OK;  // PCLBase::initCompute fails on an empty cloud: no clusters
+  float4 *pt, *sorted_pt;
+  int *src_index, *parent;
+  unsigned* bbox_ord;
+  ALLOC(pt, float4, n_keep);
+  ALLOC(sorted_pt, float4, n_keep);
+  ALLOC(src_index, int, n_keep);
+  ALLOC(parent, int, n_keep);
+  ALLOC(bbox_ord, unsigned, 6);
+  const unsigned init_ord[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+  HIPCHK(hipMemcpyAsync(bbox_ord, init_ord, sizeof(init_ord), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL((k_upon_compact<Src>), dim3(nblk(n)), dim3(kBlock), 0, s, src, c->d_fi, frame, flags, scan, pt, src_index, bbox_ord);
+  unsigned ord[6];
+  HIPCHK(hipMemcpyAsync(ord, bbox_ord, sizeof(ord), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  auto ord2f_h = [](unsigned u) { u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; float f; memcpy(&f, &u, 4); return f; };
+  UponGrid g;
+  // cells 1/16 wider than the tolerance: two points closer than the tolerance are then at most one cell
+  // apart on every axis whatever the rounding of the cell arithmetic
+  const double cell = (double)tolerance * 1.0625;
+  g.inv_cell = (float)(1.0 / cell);
+  unsigned long long dims[3];
+  for (int d = 0; d < 3; ++d) {
+    g.mn[d] = ord2f_h(ord[d]);
+    const double ext = (double)ord2f_h(ord[3 + d]) - (double)g.mn[d];
+    dims[d] = (unsigned long long)(ext * (double)g.inv_cell) + 2;
+    if (dims[d] > 0x7fffffffull) { c->err = "hope_clusters_upon_plane: tolerance too small for the extent of the cloud"; return HOPE_E_RANGE; }
+  }
+  g.nx = (unsigned)dims[0]; g.ny = (unsigned)dims[1]; g.nz = (unsigned)dims[2];
+  const long double cells = (long double)dims[0] * dims[1] * dims[2];
+  if (cells >= 9.0e18L) { c->err = "hope_clusters_upon_plane: cell grid exceeds 63 bits"; return HOPE_E_RANGE; }
+  uint64_t *keys, *keys_s;
+  uint32_t *vals, *vals_s;
+  ALLOC(keys, uint64_t, n_keep);
+  ALLOC(keys_s, uint64_t, n_keep);
+  ALLOC(vals, uint32_t, n_keep);
+  ALLOC(vals_s, uint32_t, n_keep);
+  hipLaunchKernelGGL(k_upon_keys, dim3(nblk(n_keep)), dim3(kBlock), 0, s, pt, n_keep, g, keys, vals, parent);
+  HIPCHK(sort_pairs_u64(pa, keys, keys_s, vals, vals_s, n_keep, bits_for((unsigned long long)cells), s));
+  hipLaunchKernelGGL(k_upon_gather, dim3(nblk(n_keep)), dim3(kBlock), 0, s, pt, vals_s, n_keep, sorted_pt);
+  const double tol = (double)tolerance;
+  const float r2 = (float)(tol * tol);  // KdTreeFLANN::radiusSearch: static_cast<float>(radius * radius)
+  hipLaunchKernelGGL(k_upon_union, dim3(nblk(n_keep)), dim3(kBlock), 0, s, sorted_pt, keys_s, n_keep, g, r2, parent);
+  // labels = smallest member index; a stable sort by label keeps members ascending and components in
+  // the order PCL's seed loop meets them
+  uint32_t *label = vals, *iota = vals_s, *label_s, *order, *uniq, *counts, *d_nruns;
+  ALLOC(label_s, uint32_t, n_keep);
+  ALLOC(order, uint32_t, n_keep);
+  ALLOC(uniq, uint32_t, n_keep);
+  ALLOC(counts, uint32_t, n_keep);
+  ALLOC(d_nruns, uint32_t, 1);
+  hipLaunchKernelGGL(k_upon_labels, dim3(nblk(n_keep)), dim3(kBlock), 0, s, parent, n_keep, label, iota);
+  HIPCHK(sort_pairs_u32(pa, label, label_s, iota, order, n_keep, bits_for(n_keep), s));
+  HIPCHK(rle_u32(pa, label_s, n_keep, uniq, counts, d_nruns, s));
+  ALLOC(c->d_upon_xyz, float, (size_t)n_keep * 3);
+  ALLOC(c->d_upon_src, int, n_keep);
+  hipLaunchKernelGGL(k_upon_output, dim3(nblk(n_keep)), dim3(kBlock), 0, s, pt, src_index, order, n_keep, c->d_upon_xyz, c->d_upon_src);
+  uint32_t n_runs = 0;
+  HIPCHK(hipMemcpyAsync(&n_runs, d_nruns, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  std::vector<uint32_t> h_counts(n_runs);
+  HIPCHK(hipMemcpyAsync(h_counts.data(), counts, sizeof(uint32_t) * n_runs, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipGetLastError());
+  std::vector<unsigned> first(n_runs);
+  std::vector<SizeRec> kept;
+  unsigned acc = 0;
+  for (uint32_t r = 0; r < n_runs; ++r) {
+    first[r] = acc;
+    acc += h_counts[r];
+    if ((long long)h_counts[r] >= min_size && (long long)h_counts[r] <= max_size) kept.push_back({h_counts[r], r});
+  }
+  // EuclideanClusterExtraction::extract: std::sort(clusters.rbegin(), clusters.rend(), comparePointClusters)
+  std::sort(kept.rbegin(), kept.rend(), compare_point_clusters);
+  for (const SizeRec& k : kept) c->upon.push_back({first[k.run], k.size});
+  *n_clusters = (int32_t)c->upon.size();
+  return HOPE_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+HOPE_API int hope_clusters_upon_plane(hope_ctx* c, int frame, const float* contour_xyz, int n_contour, float tolerance, int min_size,
+                                      int max_size, int32_t* n_clusters, int64_t* n_upon)
+{
+  GET_FRAME(c, frame);
+  if (!contour_xyz || n_contour < 0 || !n_clusters || !(tolerance > 0.f)) return HOPE_E_INVALID;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  if (c->upon_mark_valid) c->arena.rollback(c->upon_mark);
+  else { c->upon_mark = c->arena.mark(); c->upon_mark_valid = true; }
+  c->upon.clear();
+  *n_clusters = 0;
+  if (n_upon) *n_upon = 0;
+  const size_t n = c->src_kind == 1 ? c->dsrc.ppf : c->csrc.n;
+  if (n == 0 || F.n_raw == 0) return HOPE_OK;
+  // getCloudZInfo (utilities.cpp:751-769) and getStraightRect2D (utilities.cpp:1538-1560) of the contour: host scalars
+  std::vector<float2> h_contour(std::max(n_contour, 1));
+  float z_max = -1000.0f, mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+  for (int i = 0; i < n_contour; ++i) {
+    const float x = contour_xyz[3 * i], y = contour_xyz[3 * i + 1], z = contour_xyz[3 * i + 2];
+    h_contour[i] = make_float2(x, y);
+    if (std::isfinite(z) && z > z_max) z_max = z;
+    if (std::isfinite(x) && std::isfinite(y) && std::isfinite(z)) {
+      mnx = std::min(mnx, x); mny = std::min(mny, y); mxx = std::max(mxx, x); mxy = std::max(mxy, y);
+    }
+  }
+  if (n_contour == 0) { mnx = mny = 3.402823466e+38f; mxx = mxy = -3.402823466e+38f; }  // getMinMax3D of an empty cloud
+  UponFilter flt;
+  flt.z_thr = (double)z_max + 0.01;
+  flt.cx = (mxx + mnx) * 0.5f;
+  flt.cy = (mxy + mny) * 0.5f;
+  flt.half_w = (double)(mxx - mnx) * 0.5;
+  flt.half_h = (double)(mxy - mny) * 0.5;
+  flt.nc = n_contour;
+  float2* d_contour;
+  ALLOC(d_contour, float2, h_contour.size());
+  HIPCHK(hipMemcpyAsync(d_contour, h_contour.data(), sizeof(float2) * h_contour.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));   // h_contour is pageable and goes out of scope
+  if (c->src_kind == 1) return upon_plane(c, c->dsrc, n, frame, d_contour, flt, tolerance, min_size, max_size, n_clusters, n_upon);
+  return upon_plane(c, c->csrc, n, frame, d_contour, flt, tolerance, min_size, max_size, n_clusters, n_upon);
+}
+
+HOPE_API int hope_get_upon_cluster_sizes(hope_ctx* c, int32_t* sizes, int cap)
+{
+  if (!c || !sizes) return HOPE_E_INVALID;
+  int n = 0;
+  for (; n < (int)c->upon.size() && n < cap; ++n) sizes[n] = (int32_t)c->upon[n].count;
+  return n;
+}
+
+HOPE_API int hope_get_upon_cluster(hope_ctx* c, int cluster, float* xyz, int32_t* src_index, int cap)
+{
+  if (!c || !xyz) return HOPE_E_INVALID;
+  if (cluster < 0 || cluster >= (int)c->upon.size()) { c->err = "cluster index out of range"; return HOPE_E_RANGE; }
+  const hope_ctx::UponRange r = c->upon[cluster];
+  if (cap < (int)r.count) { c->err = "buffer too small"; return HOPE_E_RANGE; }
+  int st = copy_out(c, xyz, c->d_upon_xyz + 3 * (size_t)r.first, sizeof(float) * 3 * (size_t)r.count);
+  if (st != HOPE_OK) return st;
+  if (src_index) { st = copy_out(c, src_index, c->d_upon_src + r.first, sizeof(int) * (size_t)r.count); if (st != HOPE_OK) return st; }
+  return (int)r.count;
 }
 
 HOPE_API int hope_get_downsampled(hope_ctx* c, int frame, float* xyz)

@@ -1,5 +1,6 @@
 #include "plane_segment.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <iostream>
@@ -217,6 +218,30 @@ void PlaneSegmentRT::getHorizontalPlanes()
     std::printf("Max plane z=%.3f detected in height range %.3f, %.3f\n", max_plane_z_, min_height_, max_height_);   // :983-989
   else
     std::printf("No plane detected in height range %.3f, %.3f\n", min_height_, max_height_);
+}
+
+bool PlaneSegmentRT::getClustersUponPlane(std::vector<PointCloudMono::Ptr>& clusters)
+{
+  if (max_plane_contour_->empty()) {
+    std::cerr << "HoPE: No valid plane for extracting objects on top." << std::endl;   // plane_segment.cpp:1126-1129
+    return false;
+  }
+  std::vector<float> contour;
+  for (const PointXYZ& p : max_plane_contour_->points) { contour.push_back(p.x); contour.push_back(p.y); contour.push_back(p.z); }
+  int32_t n = 0;
+  const int st = hope_clusters_upon_plane(ctx_, 0, contour.data(), (int)max_plane_contour_->size(), 0.01f, 10, 240000, &n, nullptr);   // utilities.cpp:1397
+  if (st < 0) { std::cerr << "HoPE: " << hope_last_error(ctx_) << std::endl; return false; }
+  std::vector<int32_t> sizes((size_t)std::max(n, 1));
+  hope_get_upon_cluster_sizes(ctx_, sizes.data(), n);
+  for (int k = 0; k < n; ++k) {
+    std::vector<float> xyz((size_t)sizes[k] * 3);
+    if (hope_get_upon_cluster(ctx_, k, xyz.data(), nullptr, sizes[k]) < 0) return false;
+    PointCloudMono::Ptr cl(new PointCloudMono);
+    for (int i = 0; i < sizes[k]; ++i) cl->push_back(PointXYZ(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]));
+    clusters.push_back(cl);
+  }
+  std::printf("HoPE: Object clusters on plane #: %d\n", (int)clusters.size());   // plane_segment.cpp:1069
+  return !clusters.empty();
 }
 
 }  // namespace hope

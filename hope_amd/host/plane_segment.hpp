@@ -103,6 +103,12 @@ class PlaneSegmentRT {
   // configCallback (plane_segment.cpp:798-801)
   void configCallback(float min_height_cfg, float max_height_cfg);
 
+  // The clustering branch of postProcessing (plane_segment.cpp:1064-1070): Utilities::getClustersUponPlane
+  // (utilities.cpp:1363-1408) on src_mono_cloud_ of the last getHorizontalPlanes() with max_plane_contour_.
+  // Returns false when there is no valid contour or no cluster; pose fitting of the clusters is not part
+  // of this library.
+  bool getClustersUponPlane(std::vector<PointCloudMono::Ptr>& clusters);
+
   int last_status() const { return last_status_; }
   hope_ctx* ctx() { return ctx_; }
 

@@ -170,6 +170,26 @@ HOPE_API int hope_get_max_plane(hope_ctx* ctx, int frame, hope_max_plane* out);
  * window (findAllPlanes only, plane_segment.cpp:157-169) */
 HOPE_API int hope_last_timing(hope_ctx* ctx, double* whole_ms, double* ref_window_ms);
 
+/* ---- objects on the winning plane ------------------------
+ * replaces Utilities::getClustersUponPlane (utilities.cpp:1363-1408, caller PlaneSegmentRT::
+ * postProcessing plane_segment.cpp:1064-1070) = getCloudZInfo + getStraightRect2D of the contour,
+ * the z / rectangle / isInContour filter (utilities.cpp:1337-1360,1377-1392) over src_mono_cloud_ of
+ * `frame` of the last segment call, and Utilities::extractClusters -> pcl::EuclideanClusterExtraction
+ * (utilities.cpp:556-571: tolerance 0.01, sizes 10..240000 upstream).  The input of that segment call is
+ * read again, so a device input (on_device != 0) must still be alive and unchanged.
+ * contour_xyz: n_contour points (max_plane_contour_), 3 floats each, in hull order.
+ * Returns HOPE_OK and the number of clusters kept in *n_clusters (0 = the reference's `return false`);
+ * clusters are in the reference's order (std::sort by size, descending, as libstdc++ leaves ties).
+ * Results stay valid until the next hope_segment_* or hope_clusters_upon_plane call on the ctx. */
+HOPE_API int hope_clusters_upon_plane(hope_ctx* ctx, int frame, const float* contour_xyz, int n_contour,
+                                      float tolerance, int min_size, int max_size, int32_t* n_clusters,
+                                      int64_t* n_upon);
+/* sizes of the clusters, in output order; returns how many were written (<= cap) */
+HOPE_API int hope_get_upon_cluster_sizes(hope_ctx* ctx, int32_t* sizes, int cap);
+/* one cluster: its points (size*3 floats, ascending order of the filtered cloud `temp`) and, optionally,
+ * the index of each point in the segment call's input (pixel index for depth frames); src_index may be NULL */
+HOPE_API int hope_get_upon_cluster(hope_ctx* ctx, int cluster, float* xyz, int32_t* src_index, int cap);
+
 /* ---- one cloud across several GPUs ---------------------------------------------------
  * No counterpart in the reference (one process, one thread); SURVEY.md section 8e.  One process
  * per GPU holds a contiguous index range of the raw cloud.  The stages below are the device

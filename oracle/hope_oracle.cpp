@@ -95,6 +95,10 @@ struct hope_ctx {
   std::string err;
   double whole_ms = 0, ref_ms = 0;
   int use_bruteforce = 0;
+  // F1 results (hope_oracle_clusters_upon_plane)
+  std::vector<std::vector<int>> upon_clusters;   // indices into upon_xyz / upon_src, ascending
+  std::vector<float> upon_x, upon_y, upon_z;
+  std::vector<int> upon_src;
 };
 
 namespace {
@@ -1155,6 +1159,132 @@ ORACLE_API int hope_oracle_segment_downsampled(hope_ctx* ctx, const void* vox, s
   if (!(ctx)) return HOPE_E_INVALID;                                     \
   if ((frame) < 0 || (frame) >= (int)(ctx)->frames.size()) return HOPE_E_RANGE; \
   Frame& f = (ctx)->frames[(frame)];
+
+/* ------------------------------------------------------------------------------------
+ * F1: Utilities::getClustersUponPlane (utilities.cpp:1363-1408).
+ *  - getCloudZInfo of the contour (utilities.cpp:751-769): z_max over finite z, initial -1000;
+ *  - getStraightRect2D (utilities.cpp:1538-1560): pcl::getMinMax3D of the contour, centre and extent in float;
+ *  - per point of src_mono_cloud_: skip when `z < z_max + 0.01` (float promoted, double compare), skip when
+ *    `fabs(x - center.x) > width * 0.5` (or y / height), keep when isInContour;
+ *  - isInContour (utilities.cpp:1337-1360): sum over hull edges of |atan2(|pvi x pvj|, pvi . pvj)| in float
+ *    (Eigen Vector3f with z = 0: cross = (0, 0, ax*by - ay*bx), norm = sqrt of its square, dot = ax*bx + ay*by),
+ *    inside iff fabs(sum - 2*M_PI) < 0.01 in double.  atan2f through hope_detmath.h like every other
+ *    transcendental of the path;
+ *  - pcl::EuclideanClusterExtraction (PCL 1.8.1 segmentation/impl/extract_clusters.hpp): for each unprocessed
+ *    point in index order a breadth-first flood over radiusSearch(tolerance) (FLANN: dist2 < float(tol*tol) with
+ *    tol = (double)(float)0.01), size gate [min, max], indices sorted ascending, and finally
+ *    std::sort(clusters.rbegin(), clusters.rend(), comparePointClusters) -- called literally below (libstdc++).
+ * ---------------------------------------------------------------------------------- */
+namespace {
+bool is_in_contour(const float* cx, const float* cy, int nc, float px, float py)
+{
+  float angle_sum = 0;
+  for (int i = 0; i < nc; ++i) {
+    const int j = i + 1 < nc ? i + 1 : 0;
+    const float ax = cx[i] - px, ay = cy[i] - py, bx = cx[j] - px, by = cy[j] - py;
+    const float cz = ax * by - ay * bx;
+    const float nrm = std::sqrt(cz * cz);
+    const float dot = ax * bx + ay * by;
+    const float angle = o_atan2f(nrm, dot);
+    angle_sum += std::fabs(angle);
+  }
+  return std::fabs((double)angle_sum - 2 * M_PI) < 0.01;
+}
+struct UponCluster { std::vector<int> indices; };
+bool compare_point_clusters(const UponCluster& a, const UponCluster& b) { return a.indices.size() < b.indices.size(); }
+}  // namespace
+
+ORACLE_API int hope_oracle_clusters_upon_plane(hope_ctx* ctx, int frame, const float* contour, int n_contour, float tolerance,
+                                               int min_size, int max_size, int32_t* n_clusters, int64_t* n_upon)
+{
+  GET_FRAME(ctx, frame);
+  if (!contour || n_contour < 0 || !n_clusters) return HOPE_E_INVALID;
+  ctx->upon_clusters.clear();
+  ctx->upon_x.clear(); ctx->upon_y.clear(); ctx->upon_z.clear(); ctx->upon_src.clear();
+  *n_clusters = 0;
+  if (n_upon) *n_upon = 0;
+  std::vector<float> cx(n_contour), cy(n_contour);
+  float z_max = -1000.0f;
+  float mnx = FLT_MAX, mny = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX;
+  for (int i = 0; i < n_contour; ++i) {
+    const float x = contour[3 * i], y = contour[3 * i + 1], z = contour[3 * i + 2];
+    cx[i] = x; cy[i] = y;
+    if (std::isfinite(z) && z > z_max) z_max = z;
+    if (std::isfinite(x) && std::isfinite(y) && std::isfinite(z)) {
+      mnx = std::min(mnx, x); mny = std::min(mny, y); mxx = std::max(mxx, x); mxy = std::max(mxy, y);
+    }
+  }
+  const float center_x = (mxx + mnx) * 0.5f, center_y = (mxy + mny) * 0.5f;
+  const float width = mxx - mnx, height = mxy - mny;
+  for (size_t i = 0; i < f.tx.size(); ++i) {
+    if ((double)f.tz[i] < (double)z_max + 0.01) continue;
+    if ((double)std::fabs(f.tx[i] - center_x) > (double)width * 0.5 || (double)std::fabs(f.ty[i] - center_y) > (double)height * 0.5) continue;
+    if (!is_in_contour(cx.data(), cy.data(), n_contour, f.tx[i], f.ty[i])) continue;
+    ctx->upon_x.push_back(f.tx[i]); ctx->upon_y.push_back(f.ty[i]); ctx->upon_z.push_back(f.tz[i]);
+    ctx->upon_src.push_back(f.src_index[i]);
+  }
+  const int n = (int)ctx->upon_x.size();
+  if (n_upon) *n_upon = n;
+  if (n == 0) return HOPE_OK;   // initCompute fails on an empty cloud: no clusters
+  KdTree tree;
+  tree.init(ctx->upon_x.data(), ctx->upon_y.data(), ctx->upon_z.data(), n);
+  const double tol = (double)tolerance;
+  const float r2 = (float)(tol * tol);
+  std::vector<char> processed(n, 0);
+  std::vector<UponCluster> clusters;
+  std::vector<KdTree::DI> nn;
+  for (int i = 0; i < n; ++i) {
+    if (processed[i]) continue;
+    std::vector<int> seed_queue;
+    size_t sq_idx = 0;
+    seed_queue.push_back(i);
+    processed[i] = 1;
+    while (sq_idx < seed_queue.size()) {
+      const int q = seed_queue[sq_idx];
+      nn.clear();
+      tree.radius_rec(0, ctx->upon_x[q], ctx->upon_y[q], ctx->upon_z[q], r2, nn);
+      std::sort(nn.begin(), nn.end());
+      for (const KdTree::DI& e : nn) {
+        if (processed[e.second]) continue;
+        seed_queue.push_back(e.second);
+        processed[e.second] = 1;
+      }
+      ++sq_idx;
+    }
+    if ((long long)seed_queue.size() >= min_size && (long long)seed_queue.size() <= max_size) {
+      UponCluster r;
+      r.indices = seed_queue;
+      std::sort(r.indices.begin(), r.indices.end());
+      r.indices.erase(std::unique(r.indices.begin(), r.indices.end()), r.indices.end());
+      clusters.push_back(r);
+    }
+  }
+  std::sort(clusters.rbegin(), clusters.rend(), compare_point_clusters);
+  for (UponCluster& c : clusters) ctx->upon_clusters.push_back(std::move(c.indices));
+  *n_clusters = (int32_t)ctx->upon_clusters.size();
+  return HOPE_OK;
+}
+
+ORACLE_API int hope_oracle_get_upon_cluster_sizes(hope_ctx* ctx, int32_t* sizes, int cap)
+{
+  if (!ctx || !sizes) return HOPE_E_INVALID;
+  int n = 0;
+  for (; n < (int)ctx->upon_clusters.size() && n < cap; ++n) sizes[n] = (int32_t)ctx->upon_clusters[n].size();
+  return n;
+}
+
+ORACLE_API int hope_oracle_get_upon_cluster(hope_ctx* ctx, int cluster, float* xyz, int32_t* src_index, int cap)
+{
+  if (!ctx || !xyz) return HOPE_E_INVALID;
+  if (cluster < 0 || cluster >= (int)ctx->upon_clusters.size()) { ctx->err = "cluster index out of range"; return HOPE_E_RANGE; }
+  const std::vector<int>& idx = ctx->upon_clusters[cluster];
+  if (cap < (int)idx.size()) { ctx->err = "buffer too small"; return HOPE_E_RANGE; }
+  for (size_t k = 0; k < idx.size(); ++k) {
+    xyz[3 * k] = ctx->upon_x[idx[k]]; xyz[3 * k + 1] = ctx->upon_y[idx[k]]; xyz[3 * k + 2] = ctx->upon_z[idx[k]];
+    if (src_index) src_index[k] = ctx->upon_src[idx[k]];
+  }
+  return (int)idx.size();
+}
 
 ORACLE_API int hope_oracle_num_frames(const hope_ctx* ctx) { return ctx ? (int)ctx->frames.size() : HOPE_E_INVALID; }
 

@@ -16,3 +16,6 @@
 #define hope_get_cluster_indices hope_oracle_get_cluster_indices
 #define hope_get_max_plane hope_oracle_get_max_plane
 #define hope_last_timing hope_oracle_last_timing
+#define hope_clusters_upon_plane hope_oracle_clusters_upon_plane
+#define hope_get_upon_cluster_sizes hope_oracle_get_upon_cluster_sizes
+#define hope_get_upon_cluster hope_oracle_get_upon_cluster

@@ -28,11 +28,19 @@ int main(int argc, char** argv)
   rt.aggressive_merge_ = std::atoi(argv[11]) != 0;
   rt.cloudCallback(cloud, t, q);
   rt.getHorizontalPlanes();
+  std::vector<hope::PointCloudMono::Ptr> on_top;
+  rt.getClustersUponPlane(on_top);
   std::printf("{\"status\": %d, \"z\": %.9g, \"points\": %zu, \"area\": %.9g, \"contour\": [", rt.last_status(), rt.max_plane_z_,
               rt.max_plane_cloud_->size(), rt.max_plane_area_);
   for (size_t i = 0; i < rt.max_plane_contour_->size(); ++i) {
     const hope::PointXYZ& p = rt.max_plane_contour_->points[i];
     std::printf("%s[%.9g, %.9g, %.9g]", i ? ", " : "", p.x, p.y, p.z);
+  }
+  std::printf("], \"on_top\": [");
+  for (size_t k = 0; k < on_top.size(); ++k) {
+    double sx = 0, sy = 0, sz = 0;
+    for (const hope::PointXYZ& p : on_top[k]->points) { sx += p.x; sy += p.y; sz += p.z; }
+    std::printf("%s[%zu, %.9g, %.9g, %.9g]", k ? ", " : "", on_top[k]->size(), sx, sy, sz);
   }
   std::printf("]}\n");
   return 0;
