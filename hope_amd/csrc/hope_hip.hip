@@ -691,8 +691,12 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   ALLOC(cross, uint32_t, n_fit);
   ALLOC(edges, uint2, (size_t)n_fit * K);
   unsigned* d_n_edges = &c->d_glob->n_runs;  // free again after the voxel stage
-  hipLaunchKernelGGL(k_union_local, dim3(nblk(n_fit, kUfTile)), dim3(kBlock), 0, s, knn, fit_pt, n_fit, K,
-                     c->cfg.th_z, parent, cross);
+  if (K == 8)
+    hipLaunchKernelGGL(k_union_local<true>, dim3(nblk(n_fit, kUfTile)), dim3(kBlock), 0, s, knn, fit_pt, n_fit, K,
+                       c->cfg.th_z, parent, cross);
+  else
+    hipLaunchKernelGGL(k_union_local<false>, dim3(nblk(n_fit, kUfTile)), dim3(kBlock), 0, s, knn, fit_pt, n_fit, K,
+                       c->cfg.th_z, parent, cross);
   hipLaunchKernelGGL(k_union_cross, dim3(gb), dim3(kBlock), 0, s, knn, cross, n_fit, K, parent);
   hipLaunchKernelGGL(k_flatten_roots, dim3(gb), dim3(kBlock), 0, s, parent, rank, n_fit, root, L);
   HIPCHK(hipMemsetAsync(d_n_edges, 0, sizeof(unsigned), s));

@@ -1127,27 +1127,19 @@ __global__ void k_frame_fit_ranges(FrameInfo* fi, int n_frames, const uint32_t* 
 // and reverses [first+1, last), then splits at first+1+(n-1)/2 while n > 16.  The element
 // that ends at position p is found by walking the split chain down and undoing the
 // levels bottom-up (tests/test_seed_order.py checks this against std::sort itself).
-__device__ inline int seed_at(int n, int p)
+// rank_of walks the permutation forwards: the position at which element s of n ends up (its seed
+// rank).  Top-down, one level at a time, so no per-level state is kept (no scratch memory).
+__device__ __forceinline__ int rank_of(int n, int s)
 {
-  int fs[40], ls[40];
-  int depth = 0;
-  int f = 0, l = n;
+  int f = 0, l = n, j = s;
   while (l - f > 16) {
-    fs[depth] = f;
-    ls[depth] = l;
-    ++depth;
-    const int cut = f + 1 + (l - f - 1) / 2;
-    if (p >= cut) f = cut; else l = cut;
-  }
-  for (int d = depth - 1; d >= 0; --d) {
-    f = fs[d];
-    l = ls[d];
     const int mid = f + (l - f) / 2;
-    int s = (p == f) ? f : (l + f - p);
-    if (s == f) s = mid; else if (s == mid) s = f;
-    p = s;
+    if (j == f) j = mid; else if (j == mid) j = f;
+    if (j >= f + 1) j = l + f - j;
+    const int cut = f + 1 + (l - f - 1) / 2;
+    if (j >= cut) f = cut; else l = cut;
   }
-  return p;
+  return j;
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -1157,10 +1149,9 @@ k_seed_ranks(const FrameInfo* fi, const int* fit_frame, unsigned n_fit, int* ran
   const unsigned g = blockIdx.x * kBlock + threadIdx.x;
   if (g >= n_fit) return;
   const FrameInfo& F = fi[fit_frame[g]];
-  const int p = (int)g - F.fit_start;
-  const int s = F.fit_start + seed_at(F.n_fit, p);
-  seed_node[g] = s;  // node seeded at global rank g
-  rank[s] = (int)g;  // global rank of node s
+  const int r = F.fit_start + rank_of(F.n_fit, (int)g - F.fit_start);
+  rank[g] = r;       // global rank of node g
+  seed_node[r] = (int)g;  // node seeded at global rank r
   parent[g] = (int)g;
   L[g] = 0x7fffffff;
 }
@@ -1187,8 +1178,8 @@ __device__ __forceinline__ bool z_edge(const float4* fit_pt, int a, int b, float
 // and most of their edges join two points of the same 1024-point block: those are united in an
 // LDS union-find (no global atomics, no long pointer chases through HBM); what leaves the block
 // is noted as a bit mask per point and united in global memory by k_union_cross.
-constexpr int kUfPer = 4;
-constexpr int kUfTile = kBlock * kUfPer;
+constexpr int kUfPer = 32;
+constexpr int kUfTile = kBlock * kUfPer;  // 8192 points, 32 KiB of LDS
 
 __device__ __forceinline__ int uf_find_lds(int* parent, int x)
 {
@@ -1202,6 +1193,51 @@ __device__ __forceinline__ int uf_find_lds(int* parent, int x)
   return x;
 }
 
+// bit j set: neighbour j of g is a mutual valid edge to a larger index (each pair once, from its
+// smaller end).  K8: rows of the neighbour table are two 16-byte loads, all issued together.
+template <bool K8>
+__device__ __forceinline__ uint32_t mutual_edges_up(const int* knn, const float4* fit_pt, int g, int K, float th_z, int* nb)
+{
+  const float zg = fit_pt[g].z;
+  uint32_t m = 0u;
+  if (K8) {
+    const int4* row = reinterpret_cast<const int4*>(knn + (size_t)g * 8);
+    const int4 r0 = row[0], r1 = row[1];
+    nb[0] = r0.x; nb[1] = r0.y; nb[2] = r0.z; nb[3] = r0.w;
+    nb[4] = r1.x; nb[5] = r1.y; nb[6] = r1.z; nb[7] = r1.w;
+    float zv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zv[j] = nb[j] > g ? fit_pt[nb[j]].z : NAN;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (fabsf(zg - zv[j]) < th_z) m |= 1u << j;  // validatePoint, smooth mode (NaN: not an upward edge)
+    int4 q0[8], q1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int4* rv = reinterpret_cast<const int4*>(knn + (size_t)(nb[j] > g ? nb[j] : g) * 8);
+      q0[j] = rv[0];
+      q1[j] = rv[1];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool has = q0[j].x == g || q0[j].y == g || q0[j].z == g || q0[j].w == g || q1[j].x == g || q1[j].y == g ||
+                       q1[j].z == g || q1[j].w == g;
+      if (!has) m &= ~(1u << j);
+    }
+  } else {
+    for (int j = 0; j < K; ++j) {
+      const int v = knn[(size_t)g * K + j];
+      if (v <= g) continue;  // -1 (no neighbour), self, or the pair's larger end
+      if (!(fabsf(zg - fit_pt[v].z) < th_z)) continue;
+      bool mutual = false;
+      for (int t = 0; t < K; ++t) mutual |= (knn[(size_t)v * K + t] == g);
+      if (mutual) m |= 1u << j;
+    }
+  }
+  return m;
+}
+
+template <bool K8>
 __global__ void __launch_bounds__(kBlock)
 k_union_local(const int* knn, const float4* fit_pt, unsigned n_fit, int K, float th_z, int* parent, uint32_t* cross)
 {
@@ -1214,16 +1250,20 @@ k_union_local(const int* knn, const float4* fit_pt, unsigned n_fit, int K, float
     const int l = threadIdx.x + i * kBlock;
     const unsigned g = base + l;
     if (g >= n_fit) break;
-    const float zg = fit_pt[g].z;
+    int nb[8];  // K8 only (registers: every index is a compile-time constant)
+    uint32_t m = mutual_edges_up<K8>(knn, fit_pt, (int)g, K, th_z, nb);
     uint32_t crossmask = 0u;
-    for (int j = 0; j < K; ++j) {
-      const int v = knn[(size_t)g * K + j];
-      if (v < 0) break;
-      if (v <= (int)g) continue;  // each mutual pair once, from the smaller index
-      if (!(fabsf(zg - fit_pt[v].z) < th_z)) continue;  // validatePoint, smooth mode
-      bool mutual = false;
-      for (int t = 0; t < K; ++t) mutual |= (knn[(size_t)v * K + t] == (int)g);
-      if (!mutual) continue;
+    while (m) {
+      const int j = __ffs((int)m) - 1;
+      m &= m - 1u;
+      int v = 0;
+      if (K8) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          if (t == j) v = nb[t];
+      } else {
+        v = knn[(size_t)g * K + j];
+      }
       if ((unsigned)v >= base + kUfTile) {
         crossmask |= 1u << j;
         continue;

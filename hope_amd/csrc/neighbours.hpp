@@ -361,7 +361,7 @@ struct TileWalker {
     return (int)fminf(fmaxf(0.6f * (float)kTileCap / per_layer - 2.f * zhalo / leaf_z, 1.f), 65536.f);
   }
 
-  __device__ bool next(TileGeom& g)
+  __device__ __forceinline__ bool next(TileGeom& g)
   {
     for (int guard = 0; guard < (1 << 22); ++guard) {
       if (stage == 0) {
@@ -514,22 +514,47 @@ __device__ __forceinline__ unsigned lower_bound_z(const Cols& cols, unsigned lo,
   return lo;
 }
 
+// Entries are fetched four at a time (clamped indices, so the four reads are independent and in
+// flight together: a scan is bound by the latency of its LDS / L2 reads, not by their number) and
+// handed to fn in ascending order.
+template <class Cols, class Fn>
+__device__ __forceinline__ void for_run(const Cols& cols, unsigned lo, unsigned hi, Fn&& fn)
+{
+  for (unsigned e = lo; e < hi; e += 4u) {
+    const unsigned last = hi - 1u;
+    const float4 p0 = cols.pt(e), p1 = cols.pt(min(e + 1u, last)), p2 = cols.pt(min(e + 2u, last)),
+                 p3 = cols.pt(min(e + 3u, last));
+    fn(e, p0);
+    if (e + 1u < hi) fn(e + 1u, p1);
+    if (e + 2u < hi) fn(e + 2u, p2);
+    if (e + 3u < hi) fn(e + 3u, p3);
+  }
+}
+
 template <class Cols, class Fn>
 __device__ __forceinline__ void for_window(const Cols& cols, int x0, int x1, int cy, float zlo, float zhi, Fn&& fn)
 {
   unsigned lo, hi;
   cols.row_range(x0, x1, cy, lo, hi);
   if (hi - lo <= (unsigned)kRunDirect) {
-    for (unsigned e = lo; e < hi; ++e) fn(e, cols.pt(e));
+    for_run(cols, lo, hi, fn);
     return;
   }
   for (int cx = x0; cx <= x1; ++cx) {
     cols.range(cx, cy, lo, hi);
     if (hi - lo > 8u) lo = lower_bound_z(cols, lo, hi, zlo);
-    for (unsigned e = lo; e < hi; ++e) {
-      const float4 p = cols.pt(e);
-      if (p.z > zhi) break;
-      fn(e, p);
+    for (unsigned e = lo; e < hi; e += 4u) {
+      const unsigned last = hi - 1u;
+      const float4 p0 = cols.pt(e), p1 = cols.pt(min(e + 1u, last)), p2 = cols.pt(min(e + 2u, last)),
+                   p3 = cols.pt(min(e + 3u, last));
+      if (p0.z > zhi) break;
+      fn(e, p0);
+      if (e + 1u >= hi || p1.z > zhi) break;
+      fn(e + 1u, p1);
+      if (e + 2u >= hi || p2.z > zhi) break;
+      fn(e + 2u, p2);
+      if (e + 3u >= hi || p3.z > zhi) break;
+      fn(e + 3u, p3);
     }
   }
 }
@@ -861,9 +886,15 @@ k_knn_tile(const float4* spt, const uint32_t* col_first, const int* fit_rank, co
       if (reach2 > 0.f) {
         const int x0 = max(cqx - 2, 0), x1 = min(cqx + 2, dx - 1);
         const float zlo = q.z - zwin, zhi = q.z + zwin;
-        for (int cy = max(cqy - 2, 0); cy <= min(cqy + 2, dy - 1); ++cy)
+        // rows nearest first (0, -1, +1, -2, +2): the list fills with near points at once and most
+        // of the outer rows is then turned away by the single compare at the top of knn_offer
+#pragma unroll 1
+        for (int s = 0; s < 5; ++s) {
+          const int cy = cqy + ((s & 1) ? -((s + 1) >> 1) : (s >> 1));
+          if (cy < 0 || cy >= dy) continue;
           for_window(tc, x0, x1, cy, zlo, zhi,
                      [&](unsigned e, const float4& p) { knn_offer<Tc, KMAX>(tc, q, e, p, k, lst); });
+        }
         done = knn_kth<KMAX>(k, lst) < reach2 * reach2 * 0.999999f;
       }
       if (ablate == 2) done = true;

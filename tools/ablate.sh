@@ -1,1 +1,12 @@
-for a in 100 0; do HOPE_DEBUG_ABLATE=$a timeout -k 10 100 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/abl_prof_$a -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --frames 1024 > gpurun_out/abl_$a.log 2>&1; done
+#!/bin/bash
+# timing experiments (wrong results): HOPE_DEBUG_ABLATE = 10*knn_mode + normals_mode
+for a in "$@"; do
+  HOPE_DEBUG_ABLATE=$a timeout -k 10 100 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/abl_$a.log 2>&1 || exit 1
+  python3 - "$a" <<'PY'
+import json, sys
+a = sys.argv[1]
+d = json.loads([x for x in open(f'gpurun_out/abl_{a}.log') if x.startswith('{')][-1])
+s = {x['stage']: x['ms_per_step'] for x in d['stages']}
+print(f"ablate {a}: step {d['ms_per_step']:.2f} ms  normals {s.get('k_normals')}  knn {s.get('k_knn')} todo {s.get('k_knn_todo')}")
+PY
+done
