@@ -554,7 +554,7 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   }
   prof_close(c, ST_COLSORT, pm, 2.0 * (sizeof(CK) + 4.0) * n_vox);
   pm = prof_mark(c);
-  hipLaunchKernelGGL((k_column_table<CK>), dim3(nblk((size_t)total_cols + 1)), dim3(kBlock), 0, s, ck_out, n_vox,
+  hipLaunchKernelGGL((k_column_table<CK>), dim3(nblk((size_t)n_vox + 1)), dim3(kBlock), 0, s, ck_out, n_vox,
                      total_cols, zbits, col_first);
   hipLaunchKernelGGL(k_gather_sorted, dim3(nblk(n_vox)), dim3(kBlock), 0, s, d_vox, cv_out, n_vox, spt);
   prof_close(c, ST_COLTABLE, pm, (4.0 + 16.0 + 16.0) * n_vox + 4.0 * total_cols);
@@ -581,12 +581,16 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   hipLaunchKernelGGL(k_fit_flags, dim3(nblk((size_t)n_vox + 1)), dim3(kBlock), 0, s, d_normals, n_vox, c->th_norm,
                      flags);
   HIPCHK(exclusive_scan_u32(pa, flags, fscan, (size_t)n_vox + 1, s));
-  hipLaunchKernelGGL(k_frame_fit_ranges, dim3(nblk(F)), dim3(kBlock), 0, s, c->d_fi, F, fscan);
+  hipLaunchKernelGGL(k_frame_fit_ranges, dim3(nblk(F)), dim3(kBlock), 0, s, c->d_fi, F, fscan, c->d_glob);
+  HIPCHK(hipMemcpyAsync(&c->d_glob->pad, fscan + n_vox, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
   prof_close(c, ST_FIT, pm, (16.0 + 4.0 + 4.0 + 4.0) * n_vox);
+  {
+    int st = sync_globals(c);  // n_fit (pad) and the largest per-frame count (max_fit)
+    if (st != HOPE_OK) return st;
+  }
   uint32_t* h_cnt = reinterpret_cast<uint32_t*>(&c->h_glob->pad);
-  HIPCHK(hipMemcpyAsync(h_cnt, fscan + n_vox, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
   const unsigned n_fit = *h_cnt;
+  const unsigned max_fit = c->h_glob->max_fit;
   c->n_fit_total = n_fit;
   int* fit_rank;
   ALLOC(fit_rank, int, n_vox);
@@ -660,7 +664,7 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
       } else {
         HIPCHK(sort_pairs_u64(pa, (const uint64_t*)qk_in, (uint64_t*)qk_out, qv_in, qv_out, n_fit, cbits, s));
       }
-      hipLaunchKernelGGL((k_column_table<CK>), dim3(nblk((size_t)total_ccols + 1)), dim3(kBlock), 0, s, qk_out, n_fit,
+      hipLaunchKernelGGL((k_column_table<CK>), dim3(nblk((size_t)n_fit + 1)), dim3(kBlock), 0, s, qk_out, n_fit,
                          total_ccols, zbits, ccol_first);
       hipLaunchKernelGGL(k_gather_coarse, dim3(nblk(n_fit)), dim3(kBlock), 0, s, fit_pt, qv_out, n_fit, cspt);
       if (K <= 8)
@@ -691,13 +695,14 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   ALLOC(cross, uint32_t, n_fit);
   ALLOC(edges, uint2, (size_t)n_fit * K);
   unsigned* d_n_edges = &c->d_glob->n_runs;  // free again after the voxel stage
+  const dim3 uf_grid(std::max(1u, nblk(max_fit, kUfTile)), F);
   if (K == 8)
-    hipLaunchKernelGGL(k_union_local<true>, dim3(nblk(n_fit, kUfTile)), dim3(kBlock), 0, s, knn, fit_pt, n_fit, K,
-                       c->cfg.th_z, parent, cross);
+    hipLaunchKernelGGL(k_union_local<true>, uf_grid, dim3(kUfBlock), 0, s, knn, fit_pt, c->d_fi, K, c->cfg.th_z,
+                       parent, cross);
   else
-    hipLaunchKernelGGL(k_union_local<false>, dim3(nblk(n_fit, kUfTile)), dim3(kBlock), 0, s, knn, fit_pt, n_fit, K,
-                       c->cfg.th_z, parent, cross);
-  hipLaunchKernelGGL(k_union_cross, dim3(gb), dim3(kBlock), 0, s, knn, cross, n_fit, K, parent);
+    hipLaunchKernelGGL(k_union_local<false>, uf_grid, dim3(kUfBlock), 0, s, knn, fit_pt, c->d_fi, K, c->cfg.th_z,
+                       parent, cross);
+  hipLaunchKernelGGL(k_union_cross, dim3(gb), dim3(kBlock), 0, s, knn, cross, n_fit, K, parent, (c->ablate / 100) % 10);
   hipLaunchKernelGGL(k_flatten_roots, dim3(gb), dim3(kBlock), 0, s, parent, rank, n_fit, root, L);
   HIPCHK(hipMemsetAsync(d_n_edges, 0, sizeof(unsigned), s));
   hipLaunchKernelGGL(k_cross_edges, dim3(gb), dim3(kBlock), 0, s, knn, fit_pt, root, n_fit, K, c->cfg.th_z, edges,

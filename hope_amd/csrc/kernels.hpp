@@ -53,6 +53,7 @@ struct Globals {  // scalars produced on device, read back at the sync points
   unsigned int max_tiles; // largest per-frame count of 16x16-column tiles (neighbours.hpp)
   unsigned int total_ccols;  // entries of the coarse column table
   unsigned int n_todo;       // k-NN queries left over by the tile pass
+  unsigned int max_fit;      // largest per-frame count of fit points
 };
 
 struct DepthSrc {
@@ -910,19 +911,17 @@ k_column_keys(const float4* vox, const int* vox_frame, const FrameInfo* fi, unsi
   vals[v] = v;
 }
 
+// col_first[c] = first sorted entry whose column is >= c (c = 0 .. total_cols).  Entry i opens the
+// columns (column(i-1), column(i)]; the thread one past the end closes the table.
 template <class KeyT>
 __global__ void __launch_bounds__(kBlock)
 k_column_table(const KeyT* skeys, unsigned n_vox, unsigned total_cols, int zbits, uint32_t* col_first)
 {
-  const unsigned c = blockIdx.x * kBlock + threadIdx.x;
-  if (c > total_cols) return;
-  const KeyT target = (KeyT)c << zbits;
-  unsigned lo = 0, hi = n_vox;
-  while (lo < hi) {
-    const unsigned mid = (lo + hi) >> 1;
-    if (skeys[mid] < target) lo = mid + 1; else hi = mid;
-  }
-  col_first[c] = lo;
+  const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+  if (i > n_vox) return;
+  const long long prev = i > 0u ? (long long)(skeys[i - 1u] >> zbits) : -1ll;
+  const long long cur = i < n_vox ? (long long)(skeys[i] >> zbits) : (long long)total_cols;
+  for (long long c = prev + 1; c <= cur; ++c) col_first[c] = i;
 }
 
 // sorted copy: xyz + original (PCL-order) index in .w
@@ -1106,7 +1105,7 @@ k_fit_scatter(const uint32_t* flags, const uint32_t* scan, unsigned n_vox, const
   }
 }
 
-__global__ void k_frame_fit_ranges(FrameInfo* fi, int n_frames, const uint32_t* scan)
+__global__ void k_frame_fit_ranges(FrameInfo* fi, int n_frames, const uint32_t* scan, Globals* g)
 {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= n_frames) return;
@@ -1114,6 +1113,7 @@ __global__ void k_frame_fit_ranges(FrameInfo* fi, int n_frames, const uint32_t* 
   const unsigned b = scan[fi[f].vox_start + fi[f].n_vox];
   fi[f].fit_start = (int)a;
   fi[f].n_fit = (int)(b - a);
+  atomicMax(&g->max_fit, b - a);
 }
 
 // ---- K9: ZGrowing as min-rank reachability (z_growing.cpp:229-364) ----------------------
@@ -1178,8 +1178,9 @@ __device__ __forceinline__ bool z_edge(const float4* fit_pt, int a, int b, float
 // and most of their edges join two points of the same 1024-point block: those are united in an
 // LDS union-find (no global atomics, no long pointer chases through HBM); what leaves the block
 // is noted as a bit mask per point and united in global memory by k_union_cross.
-constexpr int kUfPer = 32;
-constexpr int kUfTile = kBlock * kUfPer;  // 8192 points, 32 KiB of LDS
+constexpr int kUfBlock = 1024;
+constexpr int kUfPer = 24;
+constexpr int kUfTile = kUfBlock * kUfPer;  // 24576 points, 96 KiB of LDS: one workgroup per CU
 
 __device__ __forceinline__ int uf_find_lds(int* parent, int x)
 {
@@ -1237,19 +1238,26 @@ __device__ __forceinline__ uint32_t mutual_edges_up(const int* knn, const float4
   return m;
 }
 
+// grid = (tiles per frame, n_frames): tiles start at the first fit point of a frame, so a frame of
+// up to kUfTile fit points is united entirely in LDS.  (Fit points are in VoxelGrid order, z layer
+// major: a cut through a frame separates layers of the same noisy surface, whose points interleave
+// everywhere -- thousands of edges across the cut and fragmented components on both sides.)
 template <bool K8>
-__global__ void __launch_bounds__(kBlock)
-k_union_local(const int* knn, const float4* fit_pt, unsigned n_fit, int K, float th_z, int* parent, uint32_t* cross)
+__global__ void __launch_bounds__(kUfBlock)
+k_union_local(const int* knn, const float4* fit_pt, const FrameInfo* fi, int K, float th_z, int* parent, uint32_t* cross)
 {
   __shared__ int s_par[kUfTile];
-  const unsigned base = blockIdx.x * kUfTile;
+  const FrameInfo& F = fi[blockIdx.y];
+  if (blockIdx.x * (unsigned)kUfTile >= (unsigned)F.n_fit) return;
+  const unsigned base = (unsigned)F.fit_start + blockIdx.x * (unsigned)kUfTile;
+  const unsigned end = min(base + (unsigned)kUfTile, (unsigned)(F.fit_start + F.n_fit));
 #pragma unroll
-  for (int i = 0; i < kUfPer; ++i) s_par[threadIdx.x + i * kBlock] = threadIdx.x + i * kBlock;
+  for (int i = 0; i < kUfPer; ++i) s_par[threadIdx.x + i * kUfBlock] = threadIdx.x + i * kUfBlock;
   __syncthreads();
   for (int i = 0; i < kUfPer; ++i) {
-    const int l = threadIdx.x + i * kBlock;
+    const int l = threadIdx.x + i * kUfBlock;
     const unsigned g = base + l;
-    if (g >= n_fit) break;
+    if (g >= end) break;
     int nb[8];  // K8 only (registers: every index is a compile-time constant)
     uint32_t m = mutual_edges_up<K8>(knn, fit_pt, (int)g, K, th_z, nb);
     uint32_t crossmask = 0u;
@@ -1264,7 +1272,7 @@ k_union_local(const int* knn, const float4* fit_pt, unsigned n_fit, int K, float
       } else {
         v = knn[(size_t)g * K + j];
       }
-      if ((unsigned)v >= base + kUfTile) {
+      if ((unsigned)v >= end) {  // (v > g >= base)
         crossmask |= 1u << j;
         continue;
       }
@@ -1285,35 +1293,49 @@ k_union_local(const int* knn, const float4* fit_pt, unsigned n_fit, int K, float
   }
   __syncthreads();
   for (int i = 0; i < kUfPer; ++i) {
-    const int l = threadIdx.x + i * kBlock;
+    const int l = threadIdx.x + i * kUfBlock;
     const unsigned g = base + l;
-    if (g >= n_fit) break;
+    if (g >= end) break;
     int r = l;
     while (s_par[r] != r) r = s_par[r];
     parent[g] = (int)base + r;
   }
 }
 
+// The mutual edges that leave a tile.  k_union_local has left parent[] flattened per tile, so an
+// edge (g, v) only says "unite tile component parent[g] with tile component parent[v]"; the many
+// edges along the cut of one surface all name the same pair, so each wave unites a pair once.
 __global__ void __launch_bounds__(kBlock)
-k_union_cross(const int* knn, const uint32_t* cross, unsigned n_fit, int K, int* parent)
+k_union_cross(const int* knn, const uint32_t* cross, unsigned n_fit, int K, int* parent, int ablate)
 {
   const unsigned g = blockIdx.x * kBlock + threadIdx.x;
-  if (g >= n_fit) return;
-  uint32_t m = cross[g];
-  while (m) {
-    const int j = __ffs((int)m) - 1;
-    m &= m - 1u;
-    int a = (int)g, b = knn[(size_t)g * K + j];
-    while (true) {
-      a = uf_find(parent, a);
-      b = uf_find(parent, b);
-      if (a == b) break;
-      if (a > b) {
-        const int t = a;
-        a = b;
-        b = t;
+  const uint32_t m = g < n_fit ? cross[g] : 0u;
+  if (__ballot(m != 0u) == 0ull || ablate == 2) return;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int ra = m ? parent[g] : 0;
+  for (int j = 0; j < K; ++j) {
+    const bool on = (m >> j) & 1u;
+    unsigned long long todo = __ballot(on);
+    if (!todo) continue;
+    const int rb = on ? parent[knn[(size_t)g * K + j]] : 0;
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int la = __shfl(ra, leader), lb = __shfl(rb, leader);
+      todo &= ~__ballot(on && ra == la && rb == lb);
+      if (lane == leader && ablate != 1) {
+        int a = la, b = lb;
+        while (true) {
+          a = uf_find(parent, a);
+          b = uf_find(parent, b);
+          if (a == b) break;
+          if (a > b) {
+            const int t = a;
+            a = b;
+            b = t;
+          }
+          if (atomicCAS(&parent[b], b, a) == b) break;
+        }
       }
-      if (atomicCAS(&parent[b], b, a) == b) break;
     }
   }
 }
@@ -1625,7 +1647,7 @@ k_cluster_verify(const uint32_t* members, const uint32_t* cl_first, const float4
 // instead of a memory round trip, which matters for the one huge cluster (a floor) that bounds
 // the kernel.  Terms that the reference skips (a non-finite z, the other side of the split)
 // enter as +0.0f, which leaves a running sum that started at +0.0f bit-identical.
-constexpr int kVTile = 1152;                      // members per tile
+constexpr int kVTile = 384;                    // members per tile
 constexpr int kVLoaders = kBlock - kWave;         // 192 loader threads
 constexpr int kVPer = kVTile / kVLoaders;         // 6 members per loader thread per tile
 constexpr int kVStride = kVTile + 4;              // LDS row stride: the 6 chain lanes hit different banks
