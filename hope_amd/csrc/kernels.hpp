@@ -1388,6 +1388,7 @@ k_flatten_roots(int* parent, const int* rank, unsigned n_fit, int* root, int* L)
 // The valid directed edges that join two DIFFERENT mutual components are the only ones the label
 // sweeps need; on real scenes they are a few percent of all edges (region fringes).  Collected
 // once (order is irrelevant: atomicMin is commutative), then swept until nothing changes.
+template <bool K8>
 __global__ void __launch_bounds__(kBlock)
 k_cross_edges(const int* knn, const float4* fit_pt, const int* root, unsigned n_fit, int K, float th_z, uint2* edges,
               unsigned* n_edges)
@@ -1397,22 +1398,50 @@ k_cross_edges(const int* knn, const float4* fit_pt, const int* root, unsigned n_
   const int r = live ? root[g] : 0;
   const float zg = live ? fit_pt[g].z : 0.f;
   const int lane = threadIdx.x & (kWave - 1);
-  for (int j = 0; j < K; ++j) {
-    bool emit = false;
-    int rv = 0;
-    if (live) {
-      const int v = knn[(size_t)g * K + j];
-      if (v >= 0 && v != (int)g) {
-        rv = root[v];
-        emit = rv != r && fabsf(zg - fit_pt[v].z) < th_z;
-      }
-    }
+  auto emit_edge = [&](bool emit, int rv) {
     const unsigned long long em = __ballot(emit);
     if (em) {
       unsigned o = 0;
       if (lane == __ffsll((long long)em) - 1) o = atomicAdd(n_edges, (unsigned)__popcll(em));
       o = (unsigned)__shfl((int)o, __ffsll((long long)em) - 1);
       if (emit) edges[o + (unsigned)__popcll(em & ((1ull << lane) - 1ull))] = make_uint2((unsigned)r, (unsigned)rv);
+    }
+  };
+  if (K8) {  // the row in two 16-byte loads, all sixteen gathers in flight together
+    int nb[8], rv[8];
+    float zv[8];
+    const int4* row = reinterpret_cast<const int4*>(knn + (size_t)(live ? g : 0u) * 8);
+    const int4 r0 = row[0], r1 = row[1];
+    nb[0] = r0.x; nb[1] = r0.y; nb[2] = r0.z; nb[3] = r0.w;
+    nb[4] = r1.x; nb[5] = r1.y; nb[6] = r1.z; nb[7] = r1.w;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool use = live && nb[j] >= 0 && nb[j] != (int)g;
+      rv[j] = use ? root[nb[j]] : r;
+      zv[j] = use ? fit_pt[nb[j]].z : NAN;
+    }
+    bool em[8];
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      em[j] = rv[j] != r && fabsf(zg - zv[j]) < th_z;
+      any |= em[j];
+    }
+    if (__ballot(any) == 0ull) return;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) emit_edge(em[j], rv[j]);
+  } else {
+    for (int j = 0; j < K; ++j) {
+      bool emit = false;
+      int rv = 0;
+      if (live) {
+        const int v = knn[(size_t)g * K + j];
+        if (v >= 0 && v != (int)g) {
+          rv = root[v];
+          emit = rv != r && fabsf(zg - fit_pt[v].z) < th_z;
+        }
+      }
+      emit_edge(emit, rv);
     }
   }
 }

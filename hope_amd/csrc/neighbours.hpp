@@ -886,14 +886,26 @@ k_knn_tile(const float4* spt, const uint32_t* col_first, const int* fit_rank, co
       if (reach2 > 0.f) {
         const int x0 = max(cqx - 2, 0), x1 = min(cqx + 2, dx - 1);
         const float zlo = q.z - zwin, zhi = q.z + zwin;
-        // rows nearest first (0, -1, +1, -2, +2): the list fills with near points at once and most
-        // of the outer rows is then turned away by the single compare at the top of knn_offer
+        // nearest columns first: the 3x3 core fills the list with near points, after which most of
+        // the outer ring is turned away by the single compare at the top of knn_offer
+        auto offer = [&](unsigned e, const float4& p) { knn_offer<Tc, KMAX>(tc, q, e, p, k, lst); };
+        const int xc0 = max(cqx - 1, 0), xc1 = min(cqx + 1, dx - 1);
+#pragma unroll 1
+        for (int s = 0; s < 3; ++s) {
+          const int cy = cqy + (s == 0 ? 0 : (s == 1 ? -1 : 1));
+          if (cy < 0 || cy >= dy) continue;
+          for_window(tc, xc0, xc1, cy, zlo, zhi, offer);
+        }
 #pragma unroll 1
         for (int s = 0; s < 5; ++s) {
-          const int cy = cqy + ((s & 1) ? -((s + 1) >> 1) : (s >> 1));
+          const int cy = cqy + s - 2;
           if (cy < 0 || cy >= dy) continue;
-          for_window(tc, x0, x1, cy, zlo, zhi,
-                     [&](unsigned e, const float4& p) { knn_offer<Tc, KMAX>(tc, q, e, p, k, lst); });
+          if (s == 0 || s == 4) {
+            for_window(tc, x0, x1, cy, zlo, zhi, offer);
+          } else {
+            if (cqx - 2 >= 0) for_window(tc, cqx - 2, cqx - 2, cy, zlo, zhi, offer);
+            if (cqx + 2 < dx) for_window(tc, cqx + 2, cqx + 2, cy, zlo, zhi, offer);
+          }
         }
         done = knn_kth<KMAX>(k, lst) < reach2 * reach2 * 0.999999f;
       }
