@@ -153,6 +153,7 @@ struct hope_ctx {
   float fast_div_key[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   int ablate = 0;             // timing experiments only (HOPE_DEBUG_ABLATE): wrong results
   int pixel_sort = 0;         // test knob: depth frames through the per-pixel sort (the cloud path's voxel stage)
+  int seg_sort = 1;           // per-frame segmented sort of the group records (HOPE_DEBUG_SEGSORT=0: device-wide sort)
   uint32_t* d_grp_cnt = nullptr;  // depth path: groups per chunk, then its exclusive scan
   uint32_t* d_grp_off = nullptr;
   unsigned cpf = 0;               // chunks per frame
@@ -480,7 +481,16 @@ int stage_voxel(hope_ctx* c, const Src& src, size_t n_per_frame, int cell_bits, 
     prof_close(c, ST_VKEYS, pm, (2.0 + sizeof(VK) + 4.0) * N);
   }
   pm = prof_mark(c);
-  if (sizeof(VK) == 4) {
+  if (sizeof(VK) == 4 && groups && c->seg_sort && M / (size_t)F < ((size_t)1 << 18)) {
+    // records are emitted frame by frame: sort the cell bits within each frame's range (many frames of
+    // modest size; one workgroup sorts a segment, so huge frames go through the device-wide sort)
+    uint32_t* seg_off;
+    ALLOC(seg_off, uint32_t, (size_t)F + 1);
+    hipLaunchKernelGGL(k_frame_record_ranges, dim3(nblk((size_t)F + 1)), dim3(kBlock), 0, s, c->d_grp_off, c->cpf, F,
+                       seg_off);
+    HIPCHK(segmented_sort_pairs_u32(pa, (const uint32_t*)k_in, (uint32_t*)k_out, v_in, v_out, M, (unsigned)F, seg_off,
+                                    cell_bits, s));
+  } else if (sizeof(VK) == 4) {
     HIPCHK(sort_pairs_u32(pa, (const uint32_t*)k_in, (uint32_t*)k_out, v_in, v_out, M, total_bits, s));
   } else {
     HIPCHK(sort_pairs_u64(pa, (const uint64_t*)k_in, (uint64_t*)k_out, v_in, v_out, M, total_bits, s));
@@ -1002,6 +1012,8 @@ HOPE_API int hope_create(const hope_config* cfg, hope_ctx** out)
   c->force_ieee_div = (knob && knob[0] == '1') ? 1 : 0;
   knob = std::getenv("HOPE_DEBUG_PIXEL_SORT");
   c->pixel_sort = (knob && knob[0] == '1') ? 1 : 0;
+  knob = std::getenv("HOPE_DEBUG_SEGSORT");
+  c->seg_sort = (knob && knob[0] == '0') ? 0 : 1;
   *out = c;
   return HOPE_OK;
 }

@@ -707,6 +707,13 @@ k_group_records(DepthSrc src, const FrameInfo* fi, float inv_xy, float inv_z, in
   }
 }
 
+// range of each frame's records in emission order (grp_off = scan of the per-chunk group counts)
+__global__ void k_frame_record_ranges(const uint32_t* grp_off, unsigned cpf, int n_frames, uint32_t* seg_off)
+{
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f <= n_frames) seg_off[f] = grp_off[(size_t)f * cpf];
+}
+
 // Centroids from the sorted group records: one lane per voxel, records in sorted (= chunk)
 // order, mask bits from 0 upwards.
 template <class KeyT, bool FAST>

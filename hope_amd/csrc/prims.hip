@@ -5,6 +5,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_run_length_encode.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
 
 namespace hope {
 
@@ -25,6 +26,21 @@ hipError_t sort_pairs_u32(const PrimAlloc& a, const uint32_t* kin, uint32_t* kou
                           uint32_t* vout, size_t n, int end_bit, hipStream_t s)
 {
   return sort_pairs_t<uint32_t>(a, kin, kout, vin, vout, n, end_bit, s);
+}
+
+hipError_t segmented_sort_pairs_u32(const PrimAlloc& a, const uint32_t* kin, uint32_t* kout, const uint32_t* vin,
+                                    uint32_t* vout, size_t n, unsigned n_segments, const uint32_t* seg_off,
+                                    int end_bit, hipStream_t s)
+{
+  if (n == 0) return hipSuccess;
+  size_t bytes = 0;
+  hipError_t e = rocprim::segmented_radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, (unsigned)n, n_segments,
+                                                     seg_off, seg_off + 1, 0u, (unsigned)end_bit, s);
+  if (e != hipSuccess) return e;
+  void* tmp = a(bytes ? bytes : 16);
+  if (!tmp) return hipErrorOutOfMemory;
+  return rocprim::segmented_radix_sort_pairs(tmp, bytes, kin, kout, vin, vout, (unsigned)n, n_segments, seg_off,
+                                             seg_off + 1, 0u, (unsigned)end_bit, s);
 }
 
 hipError_t sort_pairs_u64(const PrimAlloc& a, const uint64_t* kin, uint64_t* kout, const uint32_t* vin,

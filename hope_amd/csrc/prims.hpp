@@ -22,6 +22,10 @@ hipError_t sort_pairs_u32(const PrimAlloc& a, const uint32_t* kin, uint32_t* kou
                           uint32_t* vout, size_t n, int end_bit, hipStream_t s);
 hipError_t sort_pairs_u64(const PrimAlloc& a, const uint64_t* kin, uint64_t* kout, const uint32_t* vin,
                           uint32_t* vout, size_t n, int end_bit, hipStream_t s);
+// the same within each segment [seg_off[i], seg_off[i + 1]) (segments stay where they are)
+hipError_t segmented_sort_pairs_u32(const PrimAlloc& a, const uint32_t* kin, uint32_t* kout, const uint32_t* vin,
+                                    uint32_t* vout, size_t n, unsigned n_segments, const uint32_t* seg_off,
+                                    int end_bit, hipStream_t s);
 // run-length encode: unique[r], counts[r], *n_runs (device)
 hipError_t rle_u32(const PrimAlloc& a, const uint32_t* keys, size_t n, uint32_t* unique, uint32_t* counts,
                    uint32_t* n_runs, hipStream_t s);

@@ -195,6 +195,22 @@ def test_depth_frames_through_the_per_pixel_sort(hip_lib, oracle_lib, monkeypatc
         assert_frame_equal(o, g2, f)
 
 
+def test_group_records_through_the_device_wide_sort(hip_lib, oracle_lib, monkeypatch):
+    """The (chunk, voxel) group records are emitted frame by frame and normally sorted per frame with a
+    segmented radix sort; the knob sends them through the device-wide sort (the path of frames too large
+    for one workgroup), which must give the same bits."""
+    depth, t, q = synth_frames(3, first=33)
+    monkeypatch.setenv("HOPE_DEBUG_SEGSORT", "0")
+    g = HopeContext(hip_lib)
+    monkeypatch.delenv("HOPE_DEBUG_SEGSORT")
+    o = HopeContext(oracle_lib)
+    for c in (g, o):
+        c.set_frame_poses(t, q)
+        assert c.segment_depth(depth) == 0
+    for f in range(3):
+        assert_frame_equal(o, g, f)
+
+
 def test_knn_leftovers_through_the_coarse_index(hip_lib, oracle_lib, monkeypatch):
     """k-NN queries that the LDS tile cannot settle go through a whole-frame ring expansion: over the
     fine column index when few, over the coarse index of the fit points when many.  The knob sets the
