@@ -1,0 +1,20 @@
+#!/bin/bash
+# usage (GPU box): tools/profile_round.sh <tag>  -- everything profiles/ holds for one build:
+# bench line (with CPU baseline), rocprofv3 kernel stats of the same command, FETCH_SIZE / WRITE_SIZE passes
+# (each in its own run), the single-cloud runs and the streaming latency run.
+tag=${1:-tmp}
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out
+timeout -k 10 300 python $R/bench.py > $O/bench_$tag.json 2> $O/bench_$tag.err || { tail -5 $O/bench_$tag.err; exit 1; }
+echo "bench done"
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$tag -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/prof_$tag.log 2>&1 || { tail -5 $O/prof_$tag.log; exit 1; }
+echo "stats done"
+timeout -s KILL 150 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_$tag -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_fetch_$tag.log 2>&1 || { tail -5 $O/pmc_fetch_$tag.log; exit 1; }
+timeout -s KILL 150 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_$tag -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_write_$tag.log 2>&1 || { tail -5 $O/pmc_write_$tag.log; exit 1; }
+echo "pmc done"
+cd $R
+timeout -k 10 200 python tools/bench_cloud.py --kind multilevel --points 100000000 > $O/cloud100M_$tag.json 2> $O/cloud100M_$tag.err || { tail -5 $O/cloud100M_$tag.err; exit 1; }
+timeout -k 10 200 python tools/bench_cloud.py --kind loft --points 5000000 > $O/cloud5M_$tag.json 2> $O/cloud5M_$tag.err || { tail -5 $O/cloud5M_$tag.err; exit 1; }
+timeout -k 10 200 python tools/bench_rt.py > $O/rt_$tag.json 2> $O/rt_$tag.err || { tail -5 $O/rt_$tag.err; exit 1; }
+echo "all done"
