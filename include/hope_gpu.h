@@ -15,6 +15,10 @@
  *   - one ctx = one HIP stream + one workspace; a ctx is not thread-safe, but any number
  *     of ctxs may be used concurrently (the reference's file-scope thresholds,
  *     plane_segment.cpp:10-24, became ctx fields)
+ *   - the ctx stream is a non-blocking stream of its own: it does not wait for work queued on
+ *     the caller's streams.  A device input (on_device != 0) must be complete before the call
+ *     (synchronise the stream that produces it); every entry point returns with its own work
+ *     finished, so outputs may be read at once
  *   - results live inside the ctx until the next hope_segment_* call or hope_destroy()
  *   - "frame" = one independent extraction problem; a depth batch has n_frames of them,
  *     a cloud call has exactly one
