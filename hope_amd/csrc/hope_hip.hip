@@ -157,6 +157,7 @@ struct hope_ctx {
   uint32_t* d_grp_cnt = nullptr;  // depth path: groups per chunk, then its exclusive scan
   uint32_t* d_grp_off = nullptr;
   unsigned cpf = 0;               // chunks per frame
+  unsigned cpb = 0;               // chunks per band of kChunkRows image rows
   Prof prof;
 
   // ---- state of the last call --------------------------------------------------------
@@ -363,14 +364,16 @@ void launch_voxel_keys(hope_ctx* c, const CloudSrc& src, size_t n_per_frame, int
                      c->inv_z, cell_bits, F, k_in, v_in);
 }
 
-inline bool use_groups(const hope_ctx* c, const DepthSrc&) { return !c->pixel_sort; }
+// (the group records hold the row and column of a chunk in 16 bits each)
+inline bool use_groups(const hope_ctx* c, const DepthSrc& s) { return !c->pixel_sort && s.w <= 65535 && s.h <= 65535; }
 inline bool use_groups(const hope_ctx*, const CloudSrc&) { return false; }
 
 inline int launch_bbox(hope_ctx* c, const DepthSrc& src, size_t n_per_frame)
 {
   const int F = c->n_frames;
   if (use_groups(c, src)) {
-    c->cpf = (unsigned)((n_per_frame + kChunk - 1) / kChunk);
+    c->cpb = (unsigned)((src.w + kChunkCols - 1) / kChunkCols);
+    c->cpf = c->cpb * (unsigned)((src.h + kChunkRows - 1) / kChunkRows);
     const size_t n_chunks = (size_t)c->cpf * F;
     ALLOC(c->d_grp_cnt, uint32_t, n_chunks + 1);
     ALLOC(c->d_grp_off, uint32_t, n_chunks + 1);
@@ -378,10 +381,10 @@ inline int launch_bbox(hope_ctx* c, const DepthSrc& src, size_t n_per_frame)
     const unsigned bx = std::max(1u, std::min<unsigned>(nblk(c->cpf, (kBlock / kWave) * 16), 512u));
     if (c->fast_div)
       hipLaunchKernelGGL(k_bbox_groups<true>, dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi, c->inv_xy,
-                         c->inv_z, c->cpf, c->d_grp_cnt);
+                         c->inv_z, c->cpf, c->cpb, c->d_grp_cnt);
     else
       hipLaunchKernelGGL(k_bbox_groups<false>, dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi, c->inv_xy,
-                         c->inv_z, c->cpf, c->d_grp_cnt);
+                         c->inv_z, c->cpf, c->cpb, c->d_grp_cnt);
   } else if (depth8_ok(src)) {
     const unsigned bx = std::max(1u, std::min<unsigned>(nblk(n_per_frame / 8), 256u));
     hipLaunchKernelGGL(k_bbox_depth8, dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi);
@@ -418,10 +421,10 @@ void launch_group_records(hope_ctx* c, const DepthSrc& src, unsigned bx, int cel
 {
   if (c->fast_div)
     hipLaunchKernelGGL((k_group_records<VK, true>), dim3(bx, c->n_frames), dim3(kBlock), 0, c->stream, src, c->d_fi,
-                       c->inv_xy, c->inv_z, cell_bits, c->cpf, c->d_grp_off, rkey, rval, rec);
+                       c->inv_xy, c->inv_z, cell_bits, c->cpf, c->cpb, c->d_grp_off, rkey, rval, rec);
   else
     hipLaunchKernelGGL((k_group_records<VK, false>), dim3(bx, c->n_frames), dim3(kBlock), 0, c->stream, src, c->d_fi,
-                       c->inv_xy, c->inv_z, cell_bits, c->cpf, c->d_grp_off, rkey, rval, rec);
+                       c->inv_xy, c->inv_z, cell_bits, c->cpf, c->cpb, c->d_grp_off, rkey, rval, rec);
 }
 template <class VK>
 void launch_group_records(hope_ctx*, const CloudSrc&, unsigned, int, VK*, uint32_t*, uint4*) {}
@@ -433,10 +436,10 @@ void launch_centroids_groups(hope_ctx* c, const DepthSrc& src, const VK* uniq, c
 {
   if (c->fast_div)
     hipLaunchKernelGGL((k_centroids_groups<VK, true>), dim3(nblk(n_vox)), dim3(kBlock), 0, c->stream, src, c->d_fi,
-                       uniq, run_start, run_cnt, sval, rec, n_vox, cell_bits, c->cpf, d_vox, d_vox_frame);
+                       uniq, run_start, run_cnt, sval, rec, n_vox, cell_bits, d_vox, d_vox_frame);
   else
     hipLaunchKernelGGL((k_centroids_groups<VK, false>), dim3(nblk(n_vox)), dim3(kBlock), 0, c->stream, src, c->d_fi,
-                       uniq, run_start, run_cnt, sval, rec, n_vox, cell_bits, c->cpf, d_vox, d_vox_frame);
+                       uniq, run_start, run_cnt, sval, rec, n_vox, cell_bits, d_vox, d_vox_frame);
 }
 template <class VK>
 void launch_centroids_groups(hope_ctx*, const CloudSrc&, const VK*, const uint32_t*, const uint32_t*, const uint32_t*,

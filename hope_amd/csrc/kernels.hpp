@@ -433,13 +433,18 @@ k_voxel_keys_depth8(DepthSrc src, const FrameInfo* fi, float inv_xy, float inv_z
 }
 
 // ---- depth-frame voxel stage by (chunk, voxel) groups --------------------------------------
-// A depth image is spatially coherent: the 64 consecutive pixels of a chunk fall into a handful
-// of voxels.  Instead of sorting one (key, index) pair per pixel, the depth path sorts one
-// record per (chunk, voxel) GROUP -- about 5x fewer -- carrying the 64-bit mask of the group's
-// pixels.  Records are emitted in chunk order and the radix sort is stable, so walking a voxel's
-// records in sorted order and each mask from bit 0 upwards visits the voxel's points in
-// ascending pixel index: the same sequential float sum as VoxelGrid's (voxel_grid.hpp).
+// A depth image is spatially coherent: the 64 pixels of a small image rectangle (a chunk: kChunkRows
+// rows of kChunkCols pixels, lane = row * kChunkCols + column) fall into a handful of voxels.  Instead
+// of sorting one (key, index) pair per pixel, the depth path sorts one record per (chunk, voxel)
+// GROUP -- about 10x fewer -- carrying the 64-bit mask of the group's pixels.  Records are emitted
+// in chunk order (band of rows, then left to right) and the radix sort is stable, so a voxel's
+// records arrive band by band; within a band its pixels interleave row by row across the chunks,
+// which k_centroids_groups walks as (row, record, bit): ascending pixel index, the same sequential
+// float sum as VoxelGrid's (voxel_grid.hpp).  A 2-D chunk meets fewer voxels than 64 pixels of
+// one row: 1.95x fewer records at 4x16 than at 1x64 on the synthetic frames.
 constexpr int kChunk = 64;
+constexpr int kChunkRows = 4;
+constexpr int kChunkCols = kChunk / kChunkRows;
 
 __device__ __forceinline__ float readlane_f(float v, int lane)
 {
@@ -558,24 +563,14 @@ __device__ __forceinline__ unsigned chunk_groups(bool ok, float gx, float gy, fl
   return ng;
 }
 
-// row / column of the 64 pixels of a chunk without a per-lane integer division
-__device__ __forceinline__ void chunk_rowcol(unsigned c, int lane, unsigned w, int& row, int& col)
+// row / column of this lane's pixel of chunk c (cpb = chunks per band of rows); the divisions are
+// wave-uniform
+__device__ __forceinline__ void chunk_rowcol(unsigned c, int lane, unsigned cpb, int& row, int& col)
 {
-  const unsigned p0 = c * kChunk;  // wave-uniform
-  const unsigned r0 = p0 / w;
-  unsigned cc = p0 - r0 * w + (unsigned)lane;
-  unsigned rr = r0;
-  if (w >= (unsigned)kChunk) {
-    if (cc >= w) {
-      cc -= w;
-      ++rr;
-    }
-  } else {
-    rr += cc / w;
-    cc = cc % w;
-  }
-  row = (int)rr;
-  col = (int)cc;
+  const unsigned band = c / cpb;
+  const unsigned cib = c - band * cpb;
+  row = (int)(band * kChunkRows) + lane / kChunkCols;
+  col = (int)(cib * kChunkCols) + lane % kChunkCols;
 }
 
 // A1..A3 for the pixel at (row, col), pose in registers
@@ -596,7 +591,7 @@ __device__ __forceinline__ bool depth_point_rc(const DepthSrc& s, const float* a
 // Groups are found on the un-shifted cell triple floor(p * inv_leaf), which needs no bbox.
 template <bool FAST>
 __global__ void __launch_bounds__(kBlock)
-k_bbox_groups(DepthSrc src, FrameInfo* fi, float inv_xy, float inv_z, unsigned cpf, uint32_t* grp_cnt)
+k_bbox_groups(DepthSrc src, FrameInfo* fi, float inv_xy, float inv_z, unsigned cpf, unsigned cpb, uint32_t* grp_cnt)
 {
   const int frame = blockIdx.y;
   const int lane = threadIdx.x & (kWave - 1);
@@ -609,11 +604,11 @@ k_bbox_groups(DepthSrc src, FrameInfo* fi, float inv_xy, float inv_z, unsigned c
   float mx[3] = {-INFINITY, -INFINITY, -INFINITY};
   int cnt = 0;
   for (unsigned c = wv; c < cpf; c += nwv) {
-    const unsigned pix = c * kChunk + lane;
     int row, col;
-    chunk_rowcol(c, lane, (unsigned)src.w, row, col);
+    chunk_rowcol(c, lane, cpb, row, col);
+    const unsigned pix = (unsigned)row * (unsigned)src.w + (unsigned)col;
     float x = 0.f, y = 0.f, z = 0.f;
-    const bool ok = pix < src.ppf && depth_point_rc<FAST>(src, aff, frame, pix, row, col, x, y, z);
+    const bool ok = row < src.h && col < src.w && depth_point_rc<FAST>(src, aff, frame, pix, row, col, x, y, z);
     const float gx = floorf(x * inv_xy), gy = floorf(y * inv_xy), gz = floorf(z * inv_z);
     if (ok) {
       mn[0] = fminf(mn[0], x);
@@ -668,11 +663,11 @@ k_bbox_groups(DepthSrc src, FrameInfo* fi, float inv_xy, float inv_z, unsigned c
 }
 
 // Pass 2: one record per group: sort key = frame << cell_bits | PCL voxel index, payload =
-// (global chunk id, 64-bit pixel mask).  grp_off = exclusive scan of pass 1's counts.
+// (global chunk id, 64-bit pixel mask, row and column of the chunk's first pixel).  grp_off = exclusive scan of pass 1's counts.
 template <class KeyT, bool FAST>
 __global__ void __launch_bounds__(kBlock)
 k_group_records(DepthSrc src, const FrameInfo* fi, float inv_xy, float inv_z, int cell_bits, unsigned cpf,
-                const uint32_t* grp_off, KeyT* rkey, uint32_t* rval, uint4* rec)
+                unsigned cpb, const uint32_t* grp_off, KeyT* rkey, uint32_t* rval, uint4* rec)
 {
   const int frame = blockIdx.y;
   const int lane = threadIdx.x & (kWave - 1);
@@ -687,11 +682,11 @@ k_group_records(DepthSrc src, const FrameInfo* fi, float inv_xy, float inv_z, in
   const KeyT fbits = (KeyT)frame << cell_bits;
   const unsigned long long lt = (1ull << lane) - 1ull;
   for (unsigned c = wv; c < cpf; c += nwv) {
-    const unsigned pix = c * kChunk + lane;
     int row, col;
-    chunk_rowcol(c, lane, (unsigned)src.w, row, col);
+    chunk_rowcol(c, lane, cpb, row, col);
+    const unsigned pix = (unsigned)row * (unsigned)src.w + (unsigned)col;
     float x = 0.f, y = 0.f, z = 0.f;
-    const bool ok = pix < src.ppf && depth_point_rc<FAST>(src, aff, frame, pix, row, col, x, y, z);
+    const bool ok = row < src.h && col < src.w && depth_point_rc<FAST>(src, aff, frame, pix, row, col, x, y, z);
     const float gx = floorf(x * inv_xy), gy = floorf(y * inv_xy), gz = floorf(z * inv_z);
     unsigned long long my_grp;
     chunk_groups<true>(ok, gx, gy, gz, my_grp);
@@ -702,7 +697,9 @@ k_group_records(DepthSrc src, const FrameInfo* fi, float inv_xy, float inv_z, in
       const int i0 = (int)(gx - mb0), i1 = (int)(gy - mb1), i2 = (int)(gz - mb2);
       rkey[o] = fbits | (KeyT)(unsigned)(i0 + i1 * d0 + i2 * d01);
       rval[o] = o;
-      rec[o] = make_uint4((unsigned)cg, (unsigned)my_grp, (unsigned)(my_grp >> 32), 0u);
+      // (row, column) of the chunk's first pixel: 16 bits each (the launcher checks the image size)
+      const unsigned rc0 = (((unsigned)row - (unsigned)(lane / kChunkCols)) << 16) | ((unsigned)col - (unsigned)(lane % kChunkCols));
+      rec[o] = make_uint4((unsigned)cg, (unsigned)my_grp, (unsigned)(my_grp >> 32), rc0);
     }
   }
 }
@@ -714,13 +711,31 @@ __global__ void k_frame_record_ranges(const uint32_t* grp_off, unsigned cpf, int
   if (f <= n_frames) seg_off[f] = grp_off[(size_t)f * cpf];
 }
 
-// Centroids from the sorted group records: one lane per voxel, records in sorted (= chunk)
-// order, mask bits from 0 upwards.
+// Centroids from the sorted group records: one lane per voxel.  A voxel's records arrive band by
+// band (chunk order); the records of one band are walked row by row -- (row, record, bit) is
+// ascending pixel index.  Most voxels have one record per band, which is then walked from bit 0 up.
+template <bool FAST>
+__device__ __forceinline__ void centroid_add_bits(const DepthSrc& src, const float (&aff)[12], int frame, unsigned rc0,
+                                                  unsigned long long m, float& sx, float& sy, float& sz)
+{
+  const unsigned row0 = rc0 >> 16, col0 = rc0 & 0xffffu;
+  while (m) {
+    const int b = __ffsll((long long)m) - 1;
+    m &= m - 1ull;
+    const unsigned row = row0 + (unsigned)(b / kChunkCols), col = col0 + (unsigned)(b % kChunkCols);
+    float x = 0.f, y = 0.f, z = 0.f;
+    depth_point_rc<FAST>(src, aff, frame, row * (unsigned)src.w + col, (int)row, (int)col, x, y, z);
+    sx += x;
+    sy += y;
+    sz += z;
+  }
+}
+
 template <class KeyT, bool FAST>
 __global__ void __launch_bounds__(kBlock)
 k_centroids_groups(DepthSrc src, const FrameInfo* fi, const KeyT* unique, const uint32_t* run_start,
                    const uint32_t* run_count, const uint32_t* sval, const uint4* rec, unsigned n_vox, int cell_bits,
-                   unsigned cpf, float4* vox, int* vox_frame)
+                   float4* vox, int* vox_frame)
 {
   const unsigned v = blockIdx.x * kBlock + threadIdx.x;
   if (v >= n_vox) return;
@@ -729,23 +744,50 @@ k_centroids_groups(DepthSrc src, const FrameInfo* fi, const KeyT* unique, const 
 #pragma unroll
   for (int k = 0; k < 12; ++k) aff[k] = fi[frame].aff[k];
   const unsigned start = run_start[v], cnt = run_count[v];
-  const unsigned chunk0 = (unsigned)frame * cpf;
+  constexpr unsigned long long kRowMask = (kChunkCols == 64) ? ~0ull : ((1ull << (kChunkCols & 63)) - 1ull);
   float sx = 0.f, sy = 0.f, sz = 0.f;
   unsigned n = 0;
-  for (unsigned e = 0; e < cnt; ++e) {
-    const uint4 r = rec[sval[start + e]];
-    const unsigned base = (r.x - chunk0) * kChunk;
-    unsigned long long m = (unsigned long long)r.y | ((unsigned long long)r.z << 32);
-    n += (unsigned)__popcll(m);
-    while (m) {
-      const int b = __ffsll((long long)m) - 1;
-      m &= m - 1ull;
-      float x = 0.f, y = 0.f, z = 0.f;
-      depth_point<FAST>(src, aff, frame, base + (unsigned)b, x, y, z);
-      sx += x;
-      sy += y;
-      sz += z;
+  // (records as scalars: mask halves and the packed row/column of the chunk's first pixel)
+  unsigned r_lo, r_hi, r_rc;
+  {
+    const uint4 t = rec[sval[start]];  // every voxel has at least one record
+    r_lo = t.y;
+    r_hi = t.z;
+    r_rc = t.w;
+  }
+  for (unsigned e = 0; e < cnt;) {
+    // [e, e1): the records of one band of image rows
+    unsigned e1 = e + 1u;
+    unsigned n_lo = r_lo, n_hi = r_hi, n_rc = r_rc;
+    while (e1 < cnt) {
+      const uint4 t = rec[sval[start + e1]];
+      n_lo = t.y;
+      n_hi = t.z;
+      n_rc = t.w;
+      if ((n_rc >> 16) != (r_rc >> 16)) break;
+      ++e1;
     }
+    // one record: its bits in ascending order; several: row by row across the records
+    const int n_rows = (e1 == e + 1u) ? 1 : kChunkRows;
+    for (int row = 0; row < n_rows; ++row) {
+      for (unsigned ee = e; ee < e1; ++ee) {
+        unsigned c_lo = r_lo, c_hi = r_hi, c_rc = r_rc;
+        if (ee != e) {
+          const uint4 t = rec[sval[start + ee]];
+          c_lo = t.y;
+          c_hi = t.z;
+          c_rc = t.w;
+        }
+        unsigned long long m = (unsigned long long)c_lo | ((unsigned long long)c_hi << 32);
+        if (n_rows > 1) m &= kRowMask << (row * kChunkCols);
+        n += (unsigned)__popcll(m);
+        centroid_add_bits<FAST>(src, aff, frame, c_rc, m, sx, sy, sz);
+      }
+    }
+    e = e1;
+    r_lo = n_lo;
+    r_hi = n_hi;
+    r_rc = n_rc;
   }
   const float c = (float)n;
   vox[v] = make_float4(sx / c, sy / c, sz / c, 0.f);
