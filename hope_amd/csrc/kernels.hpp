@@ -714,20 +714,46 @@ __global__ void k_frame_record_ranges(const uint32_t* grp_off, unsigned cpf, int
 // Centroids from the sorted group records: one lane per voxel.  A voxel's records arrive band by
 // band (chunk order); the records of one band are walked row by row -- (row, record, bit) is
 // ascending pixel index.  Most voxels have one record per band, which is then walked from bit 0 up.
+// A1..A3 from an already fetched depth code (same arithmetic as depth_point_rc; the masks hold
+// surviving pixels only)
+template <bool FAST>
+__device__ __forceinline__ void depth_code_point(const DepthSrc& s, const float (&aff)[12], unsigned d, unsigned row,
+                                                 unsigned col, float& ox, float& oy, float& oz)
+{
+  const float z = div_const<FAST>((float)d, s.scale, s.rcp_scale);
+  const float x = div_const<FAST>(((float)(int)col - s.cx) * z, s.fx, s.rcp_fx);
+  const float y = div_const<FAST>(((float)(int)row - s.cy) * z, s.fy, s.rcp_fy);
+  apply_affine(aff, x, y, z, ox, oy, oz);
+}
+
+// the points of mask m (chunk at rc0) in ascending bit order, two depth reads in flight per step
 template <bool FAST>
 __device__ __forceinline__ void centroid_add_bits(const DepthSrc& src, const float (&aff)[12], int frame, unsigned rc0,
                                                   unsigned long long m, float& sx, float& sy, float& sz)
 {
   const unsigned row0 = rc0 >> 16, col0 = rc0 & 0xffffu;
+  const uint16_t* dp = src.depth + (size_t)frame * src.ppf;
   while (m) {
-    const int b = __ffsll((long long)m) - 1;
+    const int b0 = __ffsll((long long)m) - 1;
     m &= m - 1ull;
-    const unsigned row = row0 + (unsigned)(b / kChunkCols), col = col0 + (unsigned)(b % kChunkCols);
-    float x = 0.f, y = 0.f, z = 0.f;
-    depth_point_rc<FAST>(src, aff, frame, row * (unsigned)src.w + col, (int)row, (int)col, x, y, z);
+    const bool two = m != 0ull;
+    const int b1 = two ? __ffsll((long long)m) - 1 : b0;
+    m &= m - 1ull;  // (0 stays 0)
+    const unsigned ra = row0 + (unsigned)(b0 / kChunkCols), ca = col0 + (unsigned)(b0 % kChunkCols);
+    const unsigned rb = row0 + (unsigned)(b1 / kChunkCols), cb = col0 + (unsigned)(b1 % kChunkCols);
+    const unsigned da = dp[ra * (unsigned)src.w + ca];
+    const unsigned db = dp[rb * (unsigned)src.w + cb];
+    float x, y, z;
+    depth_code_point<FAST>(src, aff, da, ra, ca, x, y, z);
     sx += x;
     sy += y;
     sz += z;
+    if (two) {
+      depth_code_point<FAST>(src, aff, db, rb, cb, x, y, z);
+      sx += x;
+      sy += y;
+      sz += z;
+    }
   }
 }
 
@@ -756,32 +782,46 @@ k_centroids_groups(DepthSrc src, const FrameInfo* fi, const KeyT* unique, const 
     r_rc = t.w;
   }
   for (unsigned e = 0; e < cnt;) {
-    // [e, e1): the records of one band of image rows
+    // [e, e1): the records of one band of image rows; the second and third stay in registers
     unsigned e1 = e + 1u;
     unsigned n_lo = r_lo, n_hi = r_hi, n_rc = r_rc;
+    unsigned b_lo = 0u, b_hi = 0u, b_rc = 0u, c_lo = 0u, c_hi = 0u, c_rc = 0u;
     while (e1 < cnt) {
       const uint4 t = rec[sval[start + e1]];
       n_lo = t.y;
       n_hi = t.z;
       n_rc = t.w;
       if ((n_rc >> 16) != (r_rc >> 16)) break;
+      if (e1 == e + 1u) {
+        b_lo = n_lo;
+        b_hi = n_hi;
+        b_rc = n_rc;
+      } else if (e1 == e + 2u) {
+        c_lo = n_lo;
+        c_hi = n_hi;
+        c_rc = n_rc;
+      }
       ++e1;
     }
     // one record: its bits in ascending order; several: row by row across the records
     const int n_rows = (e1 == e + 1u) ? 1 : kChunkRows;
     for (int row = 0; row < n_rows; ++row) {
       for (unsigned ee = e; ee < e1; ++ee) {
-        unsigned c_lo = r_lo, c_hi = r_hi, c_rc = r_rc;
-        if (ee != e) {
+        unsigned m_lo, m_hi, m_rc;
+        if (ee == e) {
+          m_lo = r_lo; m_hi = r_hi; m_rc = r_rc;
+        } else if (ee == e + 1u) {
+          m_lo = b_lo; m_hi = b_hi; m_rc = b_rc;
+        } else if (ee == e + 2u) {
+          m_lo = c_lo; m_hi = c_hi; m_rc = c_rc;
+        } else {
           const uint4 t = rec[sval[start + ee]];
-          c_lo = t.y;
-          c_hi = t.z;
-          c_rc = t.w;
+          m_lo = t.y; m_hi = t.z; m_rc = t.w;
         }
-        unsigned long long m = (unsigned long long)c_lo | ((unsigned long long)c_hi << 32);
+        unsigned long long m = (unsigned long long)m_lo | ((unsigned long long)m_hi << 32);
         if (n_rows > 1) m &= kRowMask << (row * kChunkCols);
         n += (unsigned)__popcll(m);
-        centroid_add_bits<FAST>(src, aff, frame, c_rc, m, sx, sy, sz);
+        centroid_add_bits<FAST>(src, aff, frame, m_rc, m, sx, sy, sz);
       }
     }
     e = e1;
