@@ -162,7 +162,7 @@ __device__ __forceinline__ bool load_tile(const FrameInfo& F, int x0, int y0, in
       S.intp[r] = acc;
       acc += c;
     }
-    S.intp[irows] = acc;
+    for (int r = irows; r <= kTile; ++r) S.intp[r] = acc;  // (padded: interior_point searches all kTile rows)
   }
   __syncthreads();
   g.total = S.rowl[rows];
@@ -175,12 +175,13 @@ __device__ __forceinline__ bool load_tile(const FrameInfo& F, int x0, int y0, in
     S.tab[r * kTabStride + c] =
         S.rowl[r] + (col_first[col_off + (unsigned)((g.yh0 + r) * dx + g.xh0 + c)] - S.rowg[r]);
   }
-  for (unsigned i = tid; i < g.total; i += kBlock) {
-    int r = 0;
-    while (S.rowl[r + 1] <= i) ++r;
-    float4 p = spt[S.rowg[r] + (i - S.rowl[r])];
-    if (WITH_FIT) p.w = __int_as_float(fit_rank[__float_as_uint(p.w)]);
-    S.pt[i] = p;
+  for (int r = tid / kWave; r < rows; r += kBlock / kWave) {  // a wave copies a row segment: coalesced, no search
+    const unsigned gl = S.rowg[r], lo = S.rowl[r], n = S.rowl[r + 1] - lo;
+    for (unsigned i = tid % kWave; i < n; i += kWave) {
+      float4 p = spt[gl + i];
+      if (WITH_FIT) p.w = __int_as_float(fit_rank[__float_as_uint(p.w)]);
+      S.pt[lo + i] = p;
+    }
   }
   __syncthreads();
   return true;
@@ -191,8 +192,12 @@ template <bool WITH_FIT, int HALO>
 __device__ __forceinline__ void interior_point(const TileShared<WITH_FIT, HALO>& S, const TileGeom& g, unsigned i,
                                                unsigned& e_glob, unsigned& e_loc)
 {
-  int r = 0;
-  while (S.intp[r + 1] <= i) ++r;
+  static_assert(kTile == 16, "four-step search over the interior rows");
+  int r = 0;  // last row whose first point is <= i (rows past the tile's last hold the total)
+  if (S.intp[r + 8] <= i) r += 8;
+  if (S.intp[r + 4] <= i) r += 4;
+  if (S.intp[r + 2] <= i) r += 2;
+  if (S.intp[r + 1] <= i) r += 1;
   e_glob = S.intg[r] + (i - S.intp[r]);
   const int rh = r + (g.y0 - g.yh0);
   e_loc = S.rowl[rh] + (e_glob - S.rowg[rh]);
@@ -719,7 +724,7 @@ __device__ __forceinline__ float4 estimate_normal(const Cols& cols, const float4
 
 // grid = (max tiles per frame, n_frames)
 template <int CAPL>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, 3)
 k_normals_tile(const float4* spt, const uint32_t* col_first, const FrameInfo* fi, float inv_xy, float inv_z,
                float radius, float r2, int ring, float4* normals, int ablate)
 {
