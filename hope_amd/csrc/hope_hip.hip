@@ -158,6 +158,9 @@ struct hope_ctx {
   uint32_t* d_grp_off = nullptr;
   unsigned cpf = 0;               // chunks per frame
   unsigned cpb = 0;               // chunks per band of kChunkRows image rows
+  uint4* d_slots = nullptr;       // one-pass depth path: kChunk record slots per chunk (sparse)
+  int two_pass = 0;               // test knob HOPE_DEBUG_TWO_PASS: k_bbox_groups + k_group_records
+  bool one_pass = false;          // this call's records are in d_slots
   Prof prof;
 
   // ---- state of the last call --------------------------------------------------------
@@ -379,7 +382,17 @@ inline int launch_bbox(hope_ctx* c, const DepthSrc& src, size_t n_per_frame)
     ALLOC(c->d_grp_off, uint32_t, n_chunks + 1);
     HIPCHK(hipMemsetAsync(c->d_grp_cnt + n_chunks, 0, sizeof(uint32_t), c->stream));
     const unsigned bx = std::max(1u, std::min<unsigned>(nblk(c->cpf, (kBlock / kWave) * 16), 512u));
-    if (c->fast_div)
+    // one pass (records into sparse slots) unless the knob or the size of the slot array says otherwise
+    c->one_pass = !c->two_pass && n_chunks * kChunk * sizeof(uint4) <= ((size_t)16 << 30);
+    if (c->one_pass) {
+      ALLOC(c->d_slots, uint4, n_chunks * kChunk);
+      if (c->fast_div)
+        hipLaunchKernelGGL(k_bbox_records<true>, dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi, c->inv_xy,
+                           c->inv_z, c->cpf, c->cpb, c->d_grp_cnt, c->d_slots, c->d_glob);
+      else
+        hipLaunchKernelGGL(k_bbox_records<false>, dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi, c->inv_xy,
+                           c->inv_z, c->cpf, c->cpb, c->d_grp_cnt, c->d_slots, c->d_glob);
+    } else if (c->fast_div)
       hipLaunchKernelGGL(k_bbox_groups<true>, dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi, c->inv_xy,
                          c->inv_z, c->cpf, c->cpb, c->d_grp_cnt);
     else
@@ -474,7 +487,15 @@ int stage_voxel(hope_ctx* c, const Src& src, size_t n_per_frame, int cell_bits, 
   ALLOC(v_in, uint32_t, M);
   ALLOC(v_out, uint32_t, M);
   size_t pm = prof_mark(c);
-  if (groups) {
+  if (groups && c->one_pass && !c->h_glob->code_overflow) {
+    const size_t n_chunks = (size_t)c->cpf * F;
+    rec = c->d_slots;
+    hipLaunchKernelGGL((k_group_keys<VK>), dim3(nblk(n_chunks * 8)), dim3(kBlock), 0, s, c->d_fi, c->inv_xy, c->inv_z,
+                       cell_bits, c->cpf, (unsigned)n_chunks, c->d_grp_off, c->d_slots, k_in, v_in);
+    prof_close(c, ST_VKEYS, pm, 8.0 * ((double)c->cpf * F) + (4.0 + sizeof(VK) + 4.0) * M);
+  } else if (groups) {
+    // two passes: by choice, or because a cell fell outside the code range of k_bbox_records (its counts
+    // and bounding box are valid all the same)
     ALLOC(rec, uint4, M);
     const unsigned bx = std::max(1u, std::min<unsigned>(nblk(c->cpf, (kBlock / kWave) * 16), 512u));
     launch_group_records<VK>(c, src, bx, cell_bits, k_in, v_in, rec);
@@ -845,6 +866,8 @@ int run_pipeline(hope_ctx* c, const Src& src, size_t n_per_frame)
   c->prof.recs.clear();
   c->prof.used = 0;
   c->n_vox_total = c->n_fit_total = c->n_cl_total = 0;
+  c->one_pass = false;
+  c->d_slots = nullptr;
   c->h_rec.clear();
   c->h_nplanes.assign(F, 0);
   c->h_max.assign(F, hope_max_plane{});
@@ -1015,6 +1038,8 @@ HOPE_API int hope_create(const hope_config* cfg, hope_ctx** out)
   c->force_ieee_div = (knob && knob[0] == '1') ? 1 : 0;
   knob = std::getenv("HOPE_DEBUG_PIXEL_SORT");
   c->pixel_sort = (knob && knob[0] == '1') ? 1 : 0;
+  knob = std::getenv("HOPE_DEBUG_TWO_PASS");
+  c->two_pass = (knob && knob[0] == '1') ? 1 : 0;
   knob = std::getenv("HOPE_DEBUG_SEGSORT");
   c->seg_sort = (knob && knob[0] == '0') ? 0 : 1;
   *out = c;

@@ -54,6 +54,7 @@ struct Globals {  // scalars produced on device, read back at the sync points
   unsigned int total_ccols;  // entries of the coarse column table
   unsigned int n_todo;       // k-NN queries left over by the tile pass
   unsigned int max_fit;      // largest per-frame count of fit points
+  unsigned int code_overflow;  // k_bbox_records: a cell lies outside the packed code range
 };
 
 struct DepthSrc {
@@ -701,6 +702,138 @@ k_group_records(DepthSrc src, const FrameInfo* fi, float inv_xy, float inv_z, in
       const unsigned rc0 = (((unsigned)row - (unsigned)(lane / kChunkCols)) << 16) | ((unsigned)col - (unsigned)(lane % kChunkCols));
       rec[o] = make_uint4((unsigned)cg, (unsigned)my_grp, (unsigned)(my_grp >> 32), rc0);
     }
+  }
+}
+
+// ---- one pass over the depth batch instead of two ----------------------------------------------
+// k_bbox_groups + k_group_records read the batch and derive every point twice, because the sort
+// key needs the bounding box.  k_bbox_records does the per-pixel work once: it writes each group's
+// record -- with the cell as a packed code relative to the frame's camera cell, which needs no
+// bounding box -- into a fixed slot of kChunk records per chunk (a sparse array: only the slots
+// used are ever touched), next to the group count and the bounding box.  k_group_keys then turns
+// (count scan, codes, bounding box) into the dense (key, value) pairs of the sort; value = slot of
+// the record, which is what k_centroids_groups gathers.  Cells outside the code range (+-1023 cells
+// in x and y, +-511 in z around the camera) raise Globals::code_overflow and the call falls back to
+// the two passes.
+__device__ __forceinline__ void frame_ref_cell(const float* aff, float inv_xy, float inv_z, float& rx, float& ry, float& rz)
+{
+  rx = floorf(aff[9] * inv_xy);
+  ry = floorf(aff[10] * inv_xy);
+  rz = floorf(aff[11] * inv_z);
+}
+
+template <bool FAST>
+__global__ void __launch_bounds__(kBlock)
+k_bbox_records(DepthSrc src, FrameInfo* fi, float inv_xy, float inv_z, unsigned cpf, unsigned cpb, uint32_t* grp_cnt,
+               uint4* slots, Globals* g)
+{
+  const int frame = blockIdx.y;
+  const int lane = threadIdx.x & (kWave - 1);
+  const unsigned wv = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+  const unsigned nwv = gridDim.x * (kBlock / kWave);
+  float aff[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) aff[k] = fi[frame].aff[k];
+  float rx, ry, rz;
+  frame_ref_cell(aff, inv_xy, inv_z, rx, ry, rz);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  float mn[3] = {INFINITY, INFINITY, INFINITY};
+  float mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  int cnt = 0;
+  bool over = false;
+  for (unsigned c = wv; c < cpf; c += nwv) {
+    int row, col;
+    chunk_rowcol(c, lane, cpb, row, col);
+    const unsigned pix = (unsigned)row * (unsigned)src.w + (unsigned)col;
+    float x = 0.f, y = 0.f, z = 0.f;
+    const bool ok = row < src.h && col < src.w && depth_point_rc<FAST>(src, aff, frame, pix, row, col, x, y, z);
+    const float gx = floorf(x * inv_xy), gy = floorf(y * inv_xy), gz = floorf(z * inv_z);
+    if (ok) {
+      mn[0] = fminf(mn[0], x);
+      mn[1] = fminf(mn[1], y);
+      mn[2] = fminf(mn[2], z);
+      mx[0] = fmaxf(mx[0], x);
+      mx[1] = fmaxf(mx[1], y);
+      mx[2] = fmaxf(mx[2], z);
+      ++cnt;
+    }
+    unsigned long long my_grp;
+    const unsigned ng = chunk_groups<true>(ok, gx, gy, gz, my_grp);
+    const size_t cg = (size_t)frame * cpf + c;
+    if (lane == 0) grp_cnt[cg] = ng;
+    const unsigned long long leaders = __ballot(my_grp != 0ull);
+    if (my_grp) {
+      const float dx = gx - rx, dy = gy - ry, dz = gz - rz;
+      over |= !(fabsf(dx) < 1024.f && fabsf(dy) < 1024.f && fabsf(dz) < 512.f);
+      const unsigned code = (unsigned)((int)dx + 1024) | ((unsigned)((int)dy + 1024) << 11) | ((unsigned)((int)dz + 512) << 22);
+      const unsigned rc0 = (((unsigned)row - (unsigned)(lane / kChunkCols)) << 16) | ((unsigned)col - (unsigned)(lane % kChunkCols));
+      slots[cg * kChunk + (unsigned)__popcll(leaders & lt)] = make_uint4(code, (unsigned)my_grp, (unsigned)(my_grp >> 32), rc0);
+    }
+  }
+  if (__any(over) && lane == 0) g->code_overflow = 1u;
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      mn[d] = fminf(mn[d], __shfl_down(mn[d], off));
+      mx[d] = fmaxf(mx[d], __shfl_down(mx[d], off));
+    }
+    cnt += __shfl_down(cnt, off);
+  }
+  __shared__ float s_mn[kBlock / kWave][3], s_mx[kBlock / kWave][3];
+  __shared__ int s_cnt[kBlock / kWave];
+  const int w_in_b = threadIdx.x / kWave;
+  if (lane == 0) {
+    for (int d = 0; d < 3; ++d) {
+      s_mn[w_in_b][d] = mn[d];
+      s_mx[w_in_b][d] = mx[d];
+    }
+    s_cnt[w_in_b] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kBlock / kWave; ++w) {
+      for (int d = 0; d < 3; ++d) {
+        mn[d] = fminf(mn[d], s_mn[w][d]);
+        mx[d] = fmaxf(mx[d], s_mx[w][d]);
+      }
+      cnt += s_cnt[w];
+    }
+    if (cnt > 0) {
+      for (int d = 0; d < 3; ++d) {
+        atomicMin(&fi[frame].bb_min[d], f2ord(mn[d]));
+        atomicMax(&fi[frame].bb_max[d], f2ord(mx[d]));
+      }
+      atomicAdd(&fi[frame].n_raw, cnt);
+    }
+  }
+}
+
+// dense (key, value) pairs in chunk order: key = frame << cell_bits | PCL voxel index, value = slot
+// of the record.  Eight lanes per chunk (a chunk has about six groups).
+template <class KeyT>
+__global__ void __launch_bounds__(kBlock)
+k_group_keys(const FrameInfo* fi, float inv_xy, float inv_z, int cell_bits, unsigned cpf, unsigned n_chunks,
+             const uint32_t* grp_off, const uint4* slots, KeyT* rkey, uint32_t* rval)
+{
+  const unsigned t = blockIdx.x * kBlock + threadIdx.x;
+  const unsigned cg = t >> 3;
+  if (cg >= n_chunks) return;
+  const unsigned o0 = grp_off[cg], ng = grp_off[cg + 1] - o0;
+  if ((t & 7u) >= ng) return;
+  const int frame = (int)(cg / cpf);
+  const FrameInfo& F = fi[frame];
+  float rx, ry, rz;
+  frame_ref_cell(F.aff, inv_xy, inv_z, rx, ry, rz);
+  const int b0 = (int)rx - 1024 - F.min_b[0], b1 = (int)ry - 1024 - F.min_b[1], b2 = (int)rz - 512 - F.min_b[2];
+  const int d0 = F.div_b[0], d01 = F.div_b[0] * F.div_b[1];
+  const KeyT fbits = (KeyT)frame << cell_bits;
+  for (unsigned sl = t & 7u; sl < ng; sl += 8u) {
+    const unsigned slot = cg * kChunk + sl;
+    const unsigned code = slots[slot].x;
+    const int i0 = (int)(code & 2047u) + b0, i1 = (int)((code >> 11) & 2047u) + b1, i2 = (int)(code >> 22) + b2;
+    rkey[o0 + sl] = fbits | (KeyT)(unsigned)(i0 + i1 * d0 + i2 * d01);
+    rval[o0 + sl] = slot;
   }
 }
 

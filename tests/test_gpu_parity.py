@@ -211,6 +211,29 @@ def test_group_records_through_the_device_wide_sort(hip_lib, oracle_lib, monkeyp
         assert_frame_equal(o, g, f)
 
 
+def test_depth_frames_through_two_passes(hip_lib, oracle_lib, monkeypatch):
+    """Depth frames normally take one pass over the batch (k_bbox_records: records with packed cell codes in
+    sparse slots, keys made once the bounding box is known).  The knob forces the two-pass path
+    (k_bbox_groups + k_group_records), which is also the fallback when a cell leaves the code range --
+    3 mm leaves put the far floor more than 1023 cells from the camera, so that call falls back by itself."""
+    depth, t, q = synth_frames(2, first=44)
+    monkeypatch.setenv("HOPE_DEBUG_TWO_PASS", "1")
+    g = HopeContext(hip_lib)
+    monkeypatch.delenv("HOPE_DEBUG_TWO_PASS")
+    o = HopeContext(oracle_lib)
+    for c in (g, o):
+        c.set_frame_poses(t, q)
+        assert c.segment_depth(depth) == 0
+    for f in range(2):
+        assert_frame_equal(o, g, f)
+    g2, o2 = both(hip_lib, oracle_lib, th_xy=0.003, th_z=0.01)
+    for c in (g2, o2):
+        c.set_frame_poses(t, q)
+        c.segment_depth(depth)
+    for f in range(2):
+        assert_frame_equal(o2, g2, f)
+
+
 def test_knn_leftovers_through_the_coarse_index(hip_lib, oracle_lib, monkeypatch):
     """k-NN queries that the LDS tile cannot settle go through a whole-frame ring expansion: over the
     fine column index when few, over the coarse index of the fit points when many.  The knob sets the
