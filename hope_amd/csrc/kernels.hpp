@@ -859,7 +859,7 @@ __device__ __forceinline__ void depth_code_point(const DepthSrc& s, const float 
   apply_affine(aff, x, y, z, ox, oy, oz);
 }
 
-// the points of mask m (chunk at rc0) in ascending bit order, two depth reads in flight per step
+// the points of mask m (chunk at rc0) in ascending bit order, four depth reads in flight per step
 template <bool FAST>
 __device__ __forceinline__ void centroid_add_bits(const DepthSrc& src, const float (&aff)[12], int frame, unsigned rc0,
                                                   unsigned long long m, float& sx, float& sy, float& sz)
@@ -867,25 +867,27 @@ __device__ __forceinline__ void centroid_add_bits(const DepthSrc& src, const flo
   const unsigned row0 = rc0 >> 16, col0 = rc0 & 0xffffu;
   const uint16_t* dp = src.depth + (size_t)frame * src.ppf;
   while (m) {
-    const int b0 = __ffsll((long long)m) - 1;
-    m &= m - 1ull;
-    const bool two = m != 0ull;
-    const int b1 = two ? __ffsll((long long)m) - 1 : b0;
-    m &= m - 1ull;  // (0 stays 0)
-    const unsigned ra = row0 + (unsigned)(b0 / kChunkCols), ca = col0 + (unsigned)(b0 % kChunkCols);
-    const unsigned rb = row0 + (unsigned)(b1 / kChunkCols), cb = col0 + (unsigned)(b1 % kChunkCols);
-    const unsigned da = dp[ra * (unsigned)src.w + ca];
-    const unsigned db = dp[rb * (unsigned)src.w + cb];
-    float x, y, z;
-    depth_code_point<FAST>(src, aff, da, ra, ca, x, y, z);
-    sx += x;
-    sy += y;
-    sz += z;
-    if (two) {
-      depth_code_point<FAST>(src, aff, db, rb, cb, x, y, z);
-      sx += x;
-      sy += y;
-      sz += z;
+    unsigned rr[4], cc[4], dd[4];
+    bool on[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      on[i] = m != 0ull;
+      const int b = on[i] ? __ffsll((long long)m) - 1 : 0;
+      m &= m - 1ull;  // (0 stays 0)
+      rr[i] = row0 + (unsigned)(b / kChunkCols);
+      cc[i] = col0 + (unsigned)(b % kChunkCols);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dd[i] = dp[rr[i] * (unsigned)src.w + cc[i]];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (on[i]) {
+        float x, y, z;
+        depth_code_point<FAST>(src, aff, dd[i], rr[i], cc[i], x, y, z);
+        sx += x;
+        sy += y;
+        sz += z;
+      }
     }
   }
 }
