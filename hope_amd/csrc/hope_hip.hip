@@ -650,16 +650,30 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   c->d_knn = knn;
   uint32_t* todo;
   ALLOC(todo, uint32_t, n_fit);
+  // the column index of the fit points alone: the k-NN tiles then hold and scan only points that can
+  // be neighbours
+  uint32_t *sflags, *fpos, *col_first_fit;
+  float4* spt_fit;
+  ALLOC(sflags, uint32_t, (size_t)n_vox + 1);
+  ALLOC(fpos, uint32_t, (size_t)n_vox + 1);
+  ALLOC(col_first_fit, uint32_t, (size_t)total_cols + 1);
+  ALLOC(spt_fit, float4, n_fit);
   pm = prof_mark(c);
+  hipLaunchKernelGGL(k_fit_sorted_flags, dim3(nblk((size_t)n_vox + 1)), dim3(kBlock), 0, s, spt, fit_rank, n_vox, sflags);
+  HIPCHK(exclusive_scan_u32(pa, sflags, fpos, (size_t)n_vox + 1, s));
+  hipLaunchKernelGGL(k_fit_sorted_scatter, dim3(nblk(n_vox)), dim3(kBlock), 0, s, spt, fit_rank, sflags, fpos, n_vox,
+                     spt_fit);
+  hipLaunchKernelGGL(k_fit_col_table, dim3(nblk((size_t)total_cols + 1)), dim3(kBlock), 0, s, col_first, fpos,
+                     total_cols, col_first_fit);
   HIPCHK(hipMemsetAsync(&c->d_glob->n_todo, 0, sizeof(unsigned), s));
   if (K <= 8) {
-    hipLaunchKernelGGL((k_knn_tile<8>), tile_grid, dim3(kBlock), 0, s, spt, col_first, fit_rank, c->d_fi, c->inv_xy,
-                       c->inv_z, c->cfg.th_xy, K, knn, todo, &c->d_glob->n_todo, (c->ablate / 10) % 10);
+    hipLaunchKernelGGL((k_knn_tile<8>), tile_grid, dim3(kBlock), 0, s, spt_fit, col_first_fit, nullptr, c->d_fi,
+                       c->inv_xy, c->inv_z, c->cfg.th_xy, K, knn, todo, &c->d_glob->n_todo, (c->ablate / 10) % 10);
   } else {
-    hipLaunchKernelGGL((k_knn_tile<kMaxKnn>), tile_grid, dim3(kBlock), 0, s, spt, col_first, fit_rank, c->d_fi,
+    hipLaunchKernelGGL((k_knn_tile<kMaxKnn>), tile_grid, dim3(kBlock), 0, s, spt_fit, col_first_fit, nullptr, c->d_fi,
                        c->inv_xy, c->inv_z, c->cfg.th_xy, K, knn, todo, &c->d_glob->n_todo, (c->ablate / 10) % 10);
   }
-  prof_close(c, ST_KNN, pm, 16.0 * n_vox + 4.0 * K * (double)n_fit);
+  prof_close(c, ST_KNN, pm, (16.0 + 4.0 + 4.0 + 4.0) * n_vox + 4.0 * total_cols + (16.0 + 16.0 + 4.0 * K) * (double)n_fit);
   {
     int st = sync_globals(c);
     if (st != HOPE_OK) return st;
@@ -673,12 +687,13 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
     const unsigned gt = nblk(n_todo, kBlock / kWave);  // one wave per query
     if (n_todo <= std::max(c->knn_fine_limit, c->knn_fine_limit ? n_fit / 16 : 0u)) {
       if (K <= 8)
-        hipLaunchKernelGGL((k_knn_todo<GlobalCols, 8>), dim3(gt), dim3(kBlock), 0, s, todo, &c->d_glob->n_todo, fit_pt,
-                           fit_frame, spt, col_first, fit_rank, c->d_fi, c->inv_xy, c->inv_z, c->cfg.th_xy, 1, K, knn);
+        hipLaunchKernelGGL((k_knn_todo<CoarseCols, 8>), dim3(gt), dim3(kBlock), 0, s, todo, &c->d_glob->n_todo, fit_pt,
+                           fit_frame, spt_fit, col_first_fit, nullptr, c->d_fi, c->inv_xy, c->inv_z, c->cfg.th_xy, 1, K,
+                           knn);
       else
-        hipLaunchKernelGGL((k_knn_todo<GlobalCols, kMaxKnn>), dim3(gt), dim3(kBlock), 0, s, todo, &c->d_glob->n_todo,
-                           fit_pt, fit_frame, spt, col_first, fit_rank, c->d_fi, c->inv_xy, c->inv_z, c->cfg.th_xy, 1,
-                           K, knn);
+        hipLaunchKernelGGL((k_knn_todo<CoarseCols, kMaxKnn>), dim3(gt), dim3(kBlock), 0, s, todo, &c->d_glob->n_todo,
+                           fit_pt, fit_frame, spt_fit, col_first_fit, nullptr, c->d_fi, c->inv_xy, c->inv_z,
+                           c->cfg.th_xy, 1, K, knn);
     } else {
       const unsigned total_ccols = c->h_glob->total_ccols;
       CK *qk_in, *qk_out;

@@ -1194,6 +1194,36 @@ k_gather_coarse(const float4* fit_pt, const uint32_t* svals, unsigned n_fit, flo
   cspt[s] = p;
 }
 
+// ---- column index of the FIT points only (k-NN) ---------------------------------------------------
+// A stable compaction of the sorted copy keeps the (column, z) order, so the fit points need no sort
+// of their own: flags in sorted order, their scan, the compacted copy (.w = fit rank) and the column
+// table looked up through the scan.
+__global__ void __launch_bounds__(kBlock)
+k_fit_sorted_flags(const float4* spt, const int* fit_rank, unsigned n_vox, uint32_t* flags)
+{
+  const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+  if (i > n_vox) return;
+  flags[i] = (i < n_vox && fit_rank[__float_as_uint(spt[i].w)] >= 0) ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_fit_sorted_scatter(const float4* spt, const int* fit_rank, const uint32_t* flags, const uint32_t* fpos,
+                     unsigned n_vox, float4* spt_fit)
+{
+  const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_vox || !flags[i]) return;
+  float4 p = spt[i];
+  p.w = __int_as_float(fit_rank[__float_as_uint(p.w)]);
+  spt_fit[fpos[i]] = p;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_fit_col_table(const uint32_t* col_first, const uint32_t* fpos, unsigned total_cols, uint32_t* col_first_fit)
+{
+  const unsigned c = blockIdx.x * kBlock + threadIdx.x;
+  if (c <= total_cols) col_first_fit[c] = fpos[col_first[c]];
+}
+
 // FLANN L2_Simple<float>: ((dx*dx + dy*dy) + dz*dz)
 __device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, float by, float bz)
 {

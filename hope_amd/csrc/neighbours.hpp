@@ -179,7 +179,7 @@ __device__ __forceinline__ bool load_tile(const FrameInfo& F, int x0, int y0, in
     const unsigned gl = S.rowg[r], lo = S.rowl[r], n = S.rowl[r + 1] - lo;
     for (unsigned i = tid % kWave; i < n; i += kWave) {
       float4 p = spt[gl + i];
-      if (WITH_FIT) p.w = __int_as_float(fit_rank[__float_as_uint(p.w)]);
+      if (WITH_FIT && fit_rank) p.w = __int_as_float(fit_rank[__float_as_uint(p.w)]);  // (null: .w is the rank already)
       S.pt[lo + i] = p;
     }
   }
@@ -316,7 +316,7 @@ __device__ __forceinline__ void load_slab(const FrameInfo& F, float zlo_h, float
     int cc = 0;
     while (cc + 1 < width && t[cc + 1] <= i) ++cc;
     float4 p = spt[S.colg[r * width + cc] + (i - t[cc])];
-    if (WITH_FIT) p.w = __int_as_float(fit_rank[__float_as_uint(p.w)]);
+    if (WITH_FIT && fit_rank) p.w = __int_as_float(fit_rank[__float_as_uint(p.w)]);  // (null: .w is the rank already)
     S.pt[i] = p;
   }
   __syncthreads();
@@ -875,7 +875,7 @@ k_knn_tile(const float4* spt, const uint32_t* col_first, const int* fit_rank, co
     const Tc tc{S.pt, S.tab, g.xh0, g.yh0};
     if (ablate == 1) continue;
     auto leftover = [&](const float4& q, int, int) {
-      const int me = fit_rank[__float_as_uint(q.w)];
+      const int me = fit_rank ? fit_rank[__float_as_uint(q.w)] : __float_as_int(q.w);
       if (me < 0) return;
       for (int j = 0; j < K; ++j) knn_out[(size_t)me * K + j] = -1;
       todo[atomicAdd(n_todo, 1u)] = (uint32_t)me | kTodoFromRing0;
