@@ -92,6 +92,8 @@ struct TileShared {
   unsigned colg[kTW * kTW]; // slab mode: global start of the slab part of each column
   unsigned zext[2];         // slab mode: ordered-int min / max z of the region
   unsigned total;
+  unsigned nlist;           // slab mode: the interior points of the copy, compacted
+  unsigned short list[kTileCap];
 };
 
 struct TileGeom {
@@ -468,23 +470,38 @@ struct TileWalker {
 // anyway) calls fn_glob instead, with q from the sorted array (.w = PCL-order index).
 template <bool WITH_FIT, int HALO, class FnLds, class FnGlob>
 __device__ __forceinline__ void for_each_interior(const FrameInfo& F, const TileGeom& g,
-                                                  const TileShared<WITH_FIT, HALO>& S, const float4* spt,
+                                                  TileShared<WITH_FIT, HALO>& S, const float4* spt,
                                                   const uint32_t* col_first, float inv_xy, float leaf_z,
                                                   FnLds&& fn_lds, FnGlob&& fn_glob)
 {
   const int dx = F.div_b[0], dy = F.div_b[1];
-  if (g.in_lds) {
-    const unsigned n_iter = g.slab ? g.total : g.n_int;
-    for (unsigned i = threadIdx.x; i < n_iter; i += kBlock) {
-      unsigned el = i;
-      if (!g.slab) {
-        unsigned eg;
-        interior_point(S, g, i, eg, el);
-      }
+  if (g.in_lds && g.slab) {
+    // a slab copy is mostly halo (xy and z): list its interior points first, so that the queries
+    // run on full waves (order is irrelevant: every query is independent)
+    if (threadIdx.x == 0) S.nlist = 0u;
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < g.total; i += kBlock) {
+      const float4 q = S.pt[i];
+      const int cqx = clampi(cell_unclamped(q.x, inv_xy, F.min_b[0]), 0, dx - 1);
+      const int cqy = clampi(cell_unclamped(q.y, inv_xy, F.min_b[1]), 0, dy - 1);
+      if (cqx >= g.x0 && cqx < g.x1 && cqy >= g.y0 && cqy < g.y1 && q.z >= g.z0 && q.z < g.z1)
+        S.list[atomicAdd(&S.nlist, 1u)] = (unsigned short)i;
+    }
+    __syncthreads();
+    const unsigned n_list = S.nlist;
+    for (unsigned k = threadIdx.x; k < n_list; k += kBlock) {
+      const float4 q = S.pt[S.list[k]];
+      const int cqx = clampi(cell_unclamped(q.x, inv_xy, F.min_b[0]), 0, dx - 1);
+      const int cqy = clampi(cell_unclamped(q.y, inv_xy, F.min_b[1]), 0, dy - 1);
+      fn_lds(q, cqx, cqy);
+    }
+  } else if (g.in_lds) {
+    for (unsigned i = threadIdx.x; i < g.n_int; i += kBlock) {
+      unsigned eg, el;
+      interior_point(S, g, i, eg, el);
       const float4 q = S.pt[el];
       const int cqx = clampi(cell_unclamped(q.x, inv_xy, F.min_b[0]), 0, dx - 1);
       const int cqy = clampi(cell_unclamped(q.y, inv_xy, F.min_b[1]), 0, dy - 1);
-      if (g.slab && !(cqx >= g.x0 && cqx < g.x1 && cqy >= g.y0 && cqy < g.y1 && q.z >= g.z0 && q.z < g.z1)) continue;
       fn_lds(q, cqx, cqy);
     }
   } else {
@@ -854,7 +871,7 @@ constexpr uint32_t kTodoFromRing0 = 0x80000000u;  // todo flag: only part of rin
 // inside the LDS copy of its tile is answered here; the others (sparse neighbourhoods) are
 // appended to `todo` and answered by k_knn_todo.
 template <int KMAX>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, KMAX <= 8 ? 4 : 1)
 k_knn_tile(const float4* spt, const uint32_t* col_first, const int* fit_rank, const FrameInfo* fi, float inv_xy,
            float inv_z, float cell_xy, int K, int* knn_out, uint32_t* todo, unsigned* n_todo, int ablate)
 {
