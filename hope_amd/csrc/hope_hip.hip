@@ -99,11 +99,11 @@ inline unsigned nblk(size_t n, int per = kBlock) { return (unsigned)((n + per - 
 // figures come from here; off by default).
 enum Stage {
   ST_BBOX, ST_GRID, ST_VKEYS, ST_VSORT, ST_VRLE, ST_CENTROID, ST_COLKEYS, ST_COLSORT, ST_COLTABLE, ST_NORMALS,
-  ST_FIT, ST_KNN, ST_KNN_TODO, ST_LABELS, ST_SEGMENTS, ST_VERIFY, ST_COUNT
+  ST_FIT, ST_FITIDX, ST_KNN, ST_KNN_TODO, ST_LABELS, ST_SEGMENTS, ST_VERIFY, ST_COUNT
 };
 const char* const kStageNames[ST_COUNT] = {
   "k_bbox", "k_frame_grid", "k_voxel_keys", "voxel_sort(rocprim)", "voxel_rle+scan(rocprim)", "k_centroids",
-  "k_column_keys", "column_sort(rocprim)", "k_column_table+gather", "k_normals", "fit_gate+compact", "k_knn",
+  "k_column_keys", "column_sort(rocprim)", "k_column_table+gather", "k_normals", "fit_gate+compact", "fit_column_index", "k_knn",
   "k_knn_todo",
   "labels(union+sweeps)", "segments(scan+sort)", "k_cluster_verify"};
 static_assert(sizeof(kStageNames) / sizeof(kStageNames[0]) == ST_COUNT, "one name per stage");
@@ -665,6 +665,8 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
                      spt_fit);
   hipLaunchKernelGGL(k_fit_col_table, dim3(nblk((size_t)total_cols + 1)), dim3(kBlock), 0, s, col_first, fpos,
                      total_cols, col_first_fit);
+  prof_close(c, ST_FITIDX, pm, (16.0 + 4.0 + 4.0 + 8.0 + 8.0) * n_vox + 32.0 * (double)n_fit + 8.0 * total_cols);
+  pm = prof_mark(c);
   HIPCHK(hipMemsetAsync(&c->d_glob->n_todo, 0, sizeof(unsigned), s));
   if (K <= 8) {
     hipLaunchKernelGGL((k_knn_tile<8>), tile_grid, dim3(kBlock), 0, s, spt_fit, col_first_fit, nullptr, c->d_fi,
@@ -673,7 +675,7 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
     hipLaunchKernelGGL((k_knn_tile<kMaxKnn>), tile_grid, dim3(kBlock), 0, s, spt_fit, col_first_fit, nullptr, c->d_fi,
                        c->inv_xy, c->inv_z, c->cfg.th_xy, K, knn, todo, &c->d_glob->n_todo, (c->ablate / 10) % 10);
   }
-  prof_close(c, ST_KNN, pm, (16.0 + 4.0 + 4.0 + 4.0) * n_vox + 4.0 * total_cols + (16.0 + 16.0 + 4.0 * K) * (double)n_fit);
+  prof_close(c, ST_KNN, pm, (16.0 + 4.0 * K) * (double)n_fit);
   {
     int st = sync_globals(c);
     if (st != HOPE_OK) return st;
