@@ -747,21 +747,21 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   ALLOC(edges, uint2, (size_t)n_fit * K);
   unsigned* d_n_edges = &c->d_glob->n_runs;  // free again after the voxel stage
   const dim3 uf_grid(std::max(1u, nblk(max_fit, kUfTile)), F);
-  if (K == 8)
-    hipLaunchKernelGGL(k_union_local<true>, uf_grid, dim3(kUfBlock), 0, s, knn, fit_pt, c->d_fi, K, c->cfg.th_z,
-                       parent, cross);
-  else
-    hipLaunchKernelGGL(k_union_local<false>, uf_grid, dim3(kUfBlock), 0, s, knn, fit_pt, c->d_fi, K, c->cfg.th_z,
-                       parent, cross);
-  hipLaunchKernelGGL(k_union_cross, dim3(gb), dim3(kBlock), 0, s, knn, cross, n_fit, K, parent, (c->ablate / 100) % 10);
-  hipLaunchKernelGGL(k_flatten_roots, dim3(gb), dim3(kBlock), 0, s, parent, rank, n_fit, root, L);
   HIPCHK(hipMemsetAsync(d_n_edges, 0, sizeof(unsigned), s));
   if (K == 8)
-    hipLaunchKernelGGL(k_cross_edges<true>, dim3(gb), dim3(kBlock), 0, s, knn, fit_pt, root, n_fit, K, c->cfg.th_z,
-                       edges, d_n_edges);
+    hipLaunchKernelGGL(k_union_local<true>, uf_grid, dim3(kUfBlock), 0, s, knn, fit_pt, c->d_fi, K, c->cfg.th_z,
+                       parent, cross, edges, d_n_edges);
   else
-    hipLaunchKernelGGL(k_cross_edges<false>, dim3(gb), dim3(kBlock), 0, s, knn, fit_pt, root, n_fit, K, c->cfg.th_z,
-                       edges, d_n_edges);
+    hipLaunchKernelGGL(k_union_local<false>, uf_grid, dim3(kUfBlock), 0, s, knn, fit_pt, c->d_fi, K, c->cfg.th_z,
+                       parent, cross, edges, d_n_edges);
+  hipLaunchKernelGGL(k_union_cross, dim3(gb), dim3(kBlock), 0, s, knn, cross, n_fit, K, parent, (c->ablate / 100) % 10);
+  hipLaunchKernelGGL(k_flatten_roots, dim3(gb), dim3(kBlock), 0, s, parent, rank, n_fit, root, L);
+  if (K == 8)
+    hipLaunchKernelGGL(k_cross_edges<true>, dim3(gb), dim3(kBlock), 0, s, knn, fit_pt, root, fit_frame, c->d_fi, n_fit, K,
+                       c->cfg.th_z, edges, d_n_edges);
+  else
+    hipLaunchKernelGGL(k_cross_edges<false>, dim3(gb), dim3(kBlock), 0, s, knn, fit_pt, root, fit_frame, c->d_fi, n_fit,
+                       K, c->cfg.th_z, edges, d_n_edges);
   prof_close(c, ST_LABELS, pm, (2.0 * 4.0 * K + 2.0 * 16.0 + 6 * 4.0) * n_fit);
   const unsigned ge = std::min(gb, 2048u);
   for (int iter = 0; iter < 100000; ++iter) {

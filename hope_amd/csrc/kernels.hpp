@@ -1498,7 +1498,8 @@ __device__ __forceinline__ uint32_t mutual_edges_up(const int* knn, const float4
 // everywhere -- thousands of edges across the cut and fragmented components on both sides.)
 template <bool K8>
 __global__ void __launch_bounds__(kUfBlock)
-k_union_local(const int* knn, const float4* fit_pt, const FrameInfo* fi, int K, float th_z, int* parent, uint32_t* cross)
+k_union_local(const int* knn, const float4* fit_pt, const FrameInfo* fi, int K, float th_z, int* parent, uint32_t* cross,
+              uint2* edges, unsigned* n_edges)
 {
   __shared__ int s_par[kUfTile];
   const FrameInfo& F = fi[blockIdx.y];
@@ -1553,6 +1554,46 @@ k_union_local(const int* knn, const float4* fit_pt, const FrameInfo* fi, int K, 
     int r = l;
     while (s_par[r] != r) r = s_par[r];
     parent[g] = (int)base + r;
+    s_par[l] = r;  // (a walker that meets this entry jumps straight to its root)
+  }
+  // A frame that fits one tile has its final components here, in LDS: the valid one-way edges
+  // between two different components (all the label sweeps need) are found with LDS look-ups of the
+  // roots instead of k_cross_edges' gathers.
+  if (!K8 || (unsigned)F.n_fit > (unsigned)kUfTile) return;
+  __syncthreads();
+  const int lane = threadIdx.x & (kWave - 1);
+  for (int i = 0; i < kUfPer; ++i) {  // (uniform trip count: the loop holds wave-wide votes)
+    const int l = threadIdx.x + i * kUfBlock;
+    const unsigned g = base + l;
+    const bool live = g < end;
+    if (__ballot(live) == 0ull) break;
+    const int r = live ? s_par[l] : 0;
+    const float zg = live ? fit_pt[g].z : 0.f;
+    int nb[8], rv[8];
+    float zv[8];
+    const int4* row = reinterpret_cast<const int4*>(knn + (size_t)(live ? g : base) * 8);
+    const int4 r0 = row[0], r1 = row[1];
+    nb[0] = r0.x; nb[1] = r0.y; nb[2] = r0.z; nb[3] = r0.w;
+    nb[4] = r1.x; nb[5] = r1.y; nb[6] = r1.z; nb[7] = r1.w;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool use = live && nb[j] >= 0 && nb[j] != (int)g;
+      rv[j] = use ? s_par[nb[j] - (int)base] : r;
+      zv[j] = (use && rv[j] != r) ? fit_pt[nb[j]].z : NAN;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool emit = rv[j] != r && fabsf(zg - zv[j]) < th_z;
+      const unsigned long long em = __ballot(emit);
+      if (em) {
+        unsigned o = 0;
+        if (lane == __ffsll((long long)em) - 1) o = atomicAdd(n_edges, (unsigned)__popcll(em));
+        o = (unsigned)__shfl((int)o, __ffsll((long long)em) - 1);
+        if (emit)
+          edges[o + (unsigned)__popcll(em & ((1ull << lane) - 1ull))] =
+              make_uint2(base + (unsigned)r, base + (unsigned)rv[j]);
+      }
+    }
   }
 }
 
@@ -1644,11 +1685,13 @@ k_flatten_roots(int* parent, const int* rank, unsigned n_fit, int* root, int* L)
 // once (order is irrelevant: atomicMin is commutative), then swept until nothing changes.
 template <bool K8>
 __global__ void __launch_bounds__(kBlock)
-k_cross_edges(const int* knn, const float4* fit_pt, const int* root, unsigned n_fit, int K, float th_z, uint2* edges,
-              unsigned* n_edges)
+k_cross_edges(const int* knn, const float4* fit_pt, const int* root, const int* fit_frame, const FrameInfo* fi,
+              unsigned n_fit, int K, float th_z, uint2* edges, unsigned* n_edges)
 {
   const unsigned g = blockIdx.x * kBlock + threadIdx.x;
-  const bool live = g < n_fit;
+  // (K8: the edges of a frame that fits one union tile were found by k_union_local)
+  const bool live = g < n_fit && !(K8 && (unsigned)fi[fit_frame[g]].n_fit <= (unsigned)kUfTile);
+  if (__ballot(live) == 0ull) return;
   const int r = live ? root[g] : 0;
   const float zg = live ? fit_pt[g].z : 0.f;
   const int lane = threadIdx.x & (kWave - 1);
