@@ -764,10 +764,13 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
                        K, c->cfg.th_z, edges, d_n_edges);
   prof_close(c, ST_LABELS, pm, (2.0 * 4.0 * K + 2.0 * 16.0 + 6 * 4.0) * n_fit);
   const unsigned ge = std::min(gb, 2048u);
+  // Sweeps until a whole (shortcut, sweep) pair changes nothing.  Only the last pair of a batch is
+  // watched, so the usual case (a fixed point within three pairs) costs one read-back, not one per pair.
   for (int iter = 0; iter < 100000; ++iter) {
     pm = prof_mark(c);
-    HIPCHK(hipMemsetAsync(&c->d_glob->changed, 0, sizeof(unsigned), s));
-    for (int rep = 0; rep < 2; ++rep) {
+    const int pairs = iter == 0 ? 4 : 2;
+    for (int rep = 0; rep < pairs; ++rep) {
+      if (rep == pairs - 1) HIPCHK(hipMemsetAsync(&c->d_glob->changed, 0, sizeof(unsigned), s));
       hipLaunchKernelGGL(k_label_shortcut, dim3(gb), dim3(kBlock), 0, s, root, seed_node, n_fit, L,
                          &c->d_glob->changed);
       hipLaunchKernelGGL(k_label_sweep_edges, dim3(ge), dim3(kBlock), 0, s, edges, d_n_edges, L,
