@@ -72,7 +72,7 @@ ABI_SYMBOLS = [
     "frame_counts", "get_transformed", "get_downsampled", "get_normals", "get_fit_indices",
     "get_knn", "get_labels", "get_clusters", "get_cluster_indices", "get_max_plane",
     "last_timing", "grid_from_bbox", "shard_bbox", "shard_z_histogram", "shard_route",
-    "downsample_cloud_bbox", "segment_downsampled",
+    "downsample_cloud_bbox", "segment_downsampled", "segment_downsampled_staged",
     "clusters_upon_plane", "get_upon_cluster_sizes", "get_upon_cluster",
 ]
 
@@ -121,6 +121,8 @@ class HopeLib:
             "shard_route": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, i32, i32, vp, vp, i32, i32, vp, i32, vp]),
             "downsample_cloud_bbox": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, i32, vp]),
             "segment_downsampled": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, i32, vp, C.c_int64]),
+            "segment_downsampled_staged": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, i32, vp, C.c_int64, C.c_int64,
+                                                     C.c_int64, vp, vp, i32]),
             "clusters_upon_plane": (C.c_int, [vp, i32, vp, i32, C.c_float, i32, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
             "get_upon_cluster_sizes": (C.c_int, [vp, vp, i32]),
             "get_upon_cluster": (C.c_int, [vp, i32, vp, vp, i32]),
@@ -306,6 +308,14 @@ class HopeContext:
         if n:
             self._check(self.lib.fn["get_downsampled"](self._h, frame, xyz.ctypes.data), "get_downsampled")
         return xyz
+
+    def segment_downsampled_staged(self, ptr, n_vox, stride_bytes, on_device, bbox, n_raw_total, own_first,
+                                   own_count, normals_ptr=None, knn_ptr=None, stop_after=0):
+        """hope_segment_downsampled_staged: A6 / A8 for the own range only, gathered stages passed back in."""
+        b = np.ascontiguousarray(bbox, np.float32)
+        return self._check(self.lib.fn["segment_downsampled_staged"](
+            self._h, ptr, n_vox, stride_bytes, int(on_device), b.ctypes.data, int(n_raw_total), int(own_first),
+            int(own_count), normals_ptr, knn_ptr, int(stop_after)), "segment_downsampled_staged")
 
     def normals(self, frame=0):
         n = self.counts(frame).n_vox

@@ -144,6 +144,13 @@ struct hope_ctx {
   // options of the staged (multi-GPU) entry points, reset after every call
   const float* forced_bbox = nullptr;  // 6 floats: use this bounding box instead of the input's own
   int stop_after_voxel = 0;            // A5 only
+  // hope_segment_downsampled_staged: A6 / A8 for the down-sampled points [own_lo, own_hi) only, stages
+  // given from outside instead of computed, early stop after A6 (1) or A8 (2)
+  unsigned own_lo = 0u, own_hi = 0xffffffffu;
+  const float* inj_normals = nullptr;
+  const int32_t* inj_knn = nullptr;
+  int inj_on_device = 0;
+  int stop_stage = 0;
   int input_is_downsampled = 0;        // the input already is the VoxelGrid output (A6..A12 only)
   long long n_raw_override = -1;
   unsigned knn_fine_limit = 4096;  // more left-over k-NN queries than this build the coarse index (test knob)
@@ -599,14 +606,18 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   c->d_normals = d_normals;
   pm = prof_mark(c);
   const dim3 tile_grid(std::max(1u, c->h_glob->max_tiles), F);
-  if (c->normals_cap_small) {
+  if (c->inj_normals) {
+    HIPCHK(hipMemcpyAsync(d_normals, c->inj_normals, sizeof(float4) * (size_t)n_vox,
+                          c->inj_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+  } else if (c->normals_cap_small) {
     hipLaunchKernelGGL((k_normals_tile<2>), tile_grid, dim3(kBlock), 0, s, spt, col_first, c->d_fi, c->inv_xy,
-                       c->inv_z, c->radius, c->r2, c->ring, d_normals, c->ablate % 10);
+                       c->inv_z, c->radius, c->r2, c->ring, c->own_lo, c->own_hi, d_normals, c->ablate % 10);
   } else {
     hipLaunchKernelGGL((k_normals_tile<kNbCap>), tile_grid, dim3(kBlock), 0, s, spt, col_first, c->d_fi, c->inv_xy,
-                       c->inv_z, c->radius, c->r2, c->ring, d_normals, c->ablate % 10);
+                       c->inv_z, c->radius, c->r2, c->ring, c->own_lo, c->own_hi, d_normals, c->ablate % 10);
   }
   prof_close(c, ST_NORMALS, pm, (16.0 + 16.0) * n_vox);
+  if (c->stop_stage == 1) return HOPE_OK;
   // ---- A7 gate + compaction ---------------------------------------------------------
   uint32_t *flags, *fscan;
   ALLOC(flags, uint32_t, (size_t)n_vox + 1);
@@ -668,12 +679,17 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   prof_close(c, ST_FITIDX, pm, (16.0 + 4.0 + 4.0 + 8.0 + 8.0) * n_vox + 32.0 * (double)n_fit + 8.0 * total_cols);
   pm = prof_mark(c);
   HIPCHK(hipMemsetAsync(&c->d_glob->n_todo, 0, sizeof(unsigned), s));
-  if (K <= 8) {
+  if (c->inj_knn) {
+    HIPCHK(hipMemcpyAsync(knn, c->inj_knn, sizeof(int) * (size_t)n_fit * K,
+                          c->inj_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+  } else if (K <= 8) {
     hipLaunchKernelGGL((k_knn_tile<8>), tile_grid, dim3(kBlock), 0, s, spt_fit, col_first_fit, nullptr, c->d_fi,
-                       c->inv_xy, c->inv_z, c->cfg.th_xy, K, knn, todo, &c->d_glob->n_todo, (c->ablate / 10) % 10);
+                       c->inv_xy, c->inv_z, c->cfg.th_xy, K, fit_idx, c->own_lo, c->own_hi, knn, todo,
+                       &c->d_glob->n_todo, (c->ablate / 10) % 10);
   } else {
     hipLaunchKernelGGL((k_knn_tile<kMaxKnn>), tile_grid, dim3(kBlock), 0, s, spt_fit, col_first_fit, nullptr, c->d_fi,
-                       c->inv_xy, c->inv_z, c->cfg.th_xy, K, knn, todo, &c->d_glob->n_todo, (c->ablate / 10) % 10);
+                       c->inv_xy, c->inv_z, c->cfg.th_xy, K, fit_idx, c->own_lo, c->own_hi, knn, todo,
+                       &c->d_glob->n_todo, (c->ablate / 10) % 10);
   }
   prof_close(c, ST_KNN, pm, (16.0 + 4.0 * K) * (double)n_fit);
   {
@@ -729,6 +745,7 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
     }
     prof_close(c, ST_KNN_TODO, pm, (16.0 + 4.0 * K) * (double)n_todo);
   }
+  if (c->stop_stage == 2) return HOPE_OK;
   // ---- A9 region growing as min-rank reachability -----------------------------------
   int *rank, *seed_node, *parent, *L, *root, *label;
   ALLOC(rank, int, n_fit);
@@ -975,7 +992,7 @@ int run_pipeline(hope_ctx* c, const Src& src, size_t n_per_frame)
     else
       st = stage_rest<uint64_t>(c, d_vox, d_vox_frame, zbits, key2_bits);
     if (st != HOPE_OK) return st;
-    timed = c->n_fit_total > 0;
+    timed = c->n_fit_total > 0 && c->stop_stage == 0;  // (an early stop never records the closing event)
   }
   HIPCHK(hipMemcpyAsync(c->h_fi.data(), d_fi, sizeof(FrameInfo) * F, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
@@ -983,6 +1000,7 @@ int run_pipeline(hope_ctx* c, const Src& src, size_t n_per_frame)
   if (timed) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, c->ev_a, c->ev_b) == hipSuccess) c->ref_ms = ms;
+    else (void)hipGetLastError();  // (never leave a sticky error behind for the caller's own HIP calls)
   }
   if (c->n_raw_override >= 0) c->h_fi[0].n_raw = (int)c->n_raw_override;
   if (c->n_vox_total == 0)
@@ -992,7 +1010,8 @@ int run_pipeline(hope_ctx* c, const Src& src, size_t n_per_frame)
   rt_post(c);
   int worst = HOPE_OK;
   for (FrameInfo& fi : c->h_fi) {
-    fi.status = fi.n_vox == 0 ? HOPE_EMPTY : ((fi.n_fit == 0 && !c->stop_after_voxel) ? HOPE_NO_NORMAL_FIT : HOPE_OK);
+    fi.status = fi.n_vox == 0 ? HOPE_EMPTY
+                              : ((fi.n_fit == 0 && !c->stop_after_voxel && c->stop_stage != 1) ? HOPE_NO_NORMAL_FIT : HOPE_OK);
     worst = std::max(worst, fi.status);
   }
   c->whole_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1406,6 +1425,32 @@ HOPE_API int hope_segment_downsampled(hope_ctx* c, const void* vox, size_t n_vox
 {
   if (!c || !bbox) return HOPE_E_INVALID;
   return run_cloud_staged(c, vox, n_vox, stride, on_device, bbox, 0, 1, (long long)n_raw_total);
+}
+
+HOPE_API int hope_segment_downsampled_staged(hope_ctx* c, const void* vox, size_t n_vox, size_t stride, int on_device,
+                                             const float bbox[6], int64_t n_raw_total, int64_t own_first,
+                                             int64_t own_count, const float* normals_all, const int32_t* knn_all,
+                                             int stop_after)
+{
+  if (!c || !bbox) return HOPE_E_INVALID;
+  if (own_first < 0 || own_count < 0 || (uint64_t)(own_first + own_count) > n_vox || stop_after < 0 || stop_after > 2 ||
+      (knn_all && !normals_all)) {
+    c->err = "hope_segment_downsampled_staged: bad argument";
+    return HOPE_E_INVALID;
+  }
+  c->own_lo = (unsigned)own_first;
+  c->own_hi = (unsigned)(own_first + own_count);
+  c->inj_normals = normals_all;
+  c->inj_knn = knn_all;
+  c->inj_on_device = on_device;
+  c->stop_stage = stop_after;
+  const int st = run_cloud_staged(c, vox, n_vox, stride, on_device, bbox, 0, 1, (long long)n_raw_total);
+  c->own_lo = 0u;
+  c->own_hi = 0xffffffffu;
+  c->inj_normals = nullptr;
+  c->inj_knn = nullptr;
+  c->stop_stage = 0;
+  return st;
 }
 
 #define GET_FRAME(c, frame)                                   \

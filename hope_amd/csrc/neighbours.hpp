@@ -743,7 +743,7 @@ __device__ __forceinline__ float4 estimate_normal(const Cols& cols, const float4
 template <int CAPL>
 __global__ void __launch_bounds__(kBlock, 3)
 k_normals_tile(const float4* spt, const uint32_t* col_first, const FrameInfo* fi, float inv_xy, float inv_z,
-               float radius, float r2, int ring, float4* normals, int ablate)
+               float radius, float r2, int ring, unsigned own_lo, unsigned own_hi, float4* normals, int ablate)
 {
   __shared__ TileShared<false, kHaloNormals> S;
   __shared__ unsigned short s_cand_e[CAPL * kBlock];
@@ -762,11 +762,15 @@ k_normals_tile(const float4* spt, const uint32_t* col_first, const FrameInfo* fi
     for_each_interior(
         F, g, S, spt, col_first, inv_xy, leaf_z,
         [&](const float4& q, int cqx, int cqy) {
-          normals[__float_as_uint(q.w)] = estimate_normal<TileCols<kHaloNormals>, CAPL>(
-              tc, q, cqx, cqy, dx, dy, ring, radius, r2, leaf_z, cand_e, ablate);
+          const unsigned idx = __float_as_uint(q.w);
+          if (idx < own_lo || idx >= own_hi) return;  // (staged multi-GPU call: another rank's point)
+          normals[idx] = estimate_normal<TileCols<kHaloNormals>, CAPL>(tc, q, cqx, cqy, dx, dy, ring, radius, r2, leaf_z,
+                                                                       cand_e, ablate);
         },
         [&](const float4& q, int cqx, int cqy) {
-          normals[__float_as_uint(q.w)] =
+          const unsigned idx = __float_as_uint(q.w);
+          if (idx < own_lo || idx >= own_hi) return;
+          normals[idx] =
               estimate_normal<GlobalCols, CAPL>(gc, q, cqx, cqy, dx, dy, ring, radius, r2, leaf_z, cand_e, ablate);
         });
   }
@@ -873,7 +877,8 @@ constexpr uint32_t kTodoFromRing0 = 0x80000000u;  // todo flag: only part of rin
 template <int KMAX>
 __global__ void __launch_bounds__(kBlock, KMAX <= 8 ? 4 : 1)
 k_knn_tile(const float4* spt, const uint32_t* col_first, const int* fit_rank, const FrameInfo* fi, float inv_xy,
-           float inv_z, float cell_xy, int K, int* knn_out, uint32_t* todo, unsigned* n_todo, int ablate)
+           float inv_z, float cell_xy, int K, const uint32_t* fit_idx, unsigned own_lo, unsigned own_hi, int* knn_out,
+           uint32_t* todo, unsigned* n_todo, int ablate)
 {
   typedef TileCols<kHaloKnn> Tc;
   __shared__ TileShared<true, kHaloKnn> S;
@@ -894,12 +899,17 @@ k_knn_tile(const float4* spt, const uint32_t* col_first, const int* fit_rank, co
     auto leftover = [&](const float4& q, int, int) {
       const int me = fit_rank ? fit_rank[__float_as_uint(q.w)] : __float_as_int(q.w);
       if (me < 0) return;
+      if (fit_idx[me] < own_lo || fit_idx[me] >= own_hi) return;
       for (int j = 0; j < K; ++j) knn_out[(size_t)me * K + j] = -1;
       todo[atomicAdd(n_todo, 1u)] = (uint32_t)me | kTodoFromRing0;
     };
     for_each_interior(F, g, S, spt, col_first, inv_xy, leaf_z, [&](const float4& q, int cqx, int cqy) {
       const int me = __float_as_int(q.w);
       if (me < 0) return;
+      if (own_hi - own_lo != 0xffffffffu) {  // staged multi-GPU call: only this rank's share of the queries
+        const unsigned idx = fit_idx[me];
+        if (idx < own_lo || idx >= own_hi) return;
+      }
       knn_key lst[KMAX];
 #pragma unroll
       for (int j = 0; j < KMAX; ++j) lst[j] = kKnnEmpty;

@@ -8,8 +8,9 @@ A single large cloud (configs 3/4) is sharded by contiguous point range; the raw
 exchanges the path really needs sit between the stages: a MIN/MAX all-reduce of the bounding box
 (6 floats), a SUM all-reduce of the int64 z-layer histogram (a few hundred bins), one all-to-all
 that sends every surviving point to the rank owning its z band, and one all-gather of the
-down-sampled cloud (~N_raw/10..40 points).  A6..A12 then run on the gathered down-sampled cloud;
-see segment_cloud_sharded.  Every step is bit-identical to the single-process path."""
+down-sampled cloud (~N_raw/10..40 points).  A6..A12 then run on the gathered down-sampled cloud, the
+two neighbour searches (A6 normals, A8 k-NN) shared between the ranks by z band with an all-gather of
+the normals and one of the k-NN rows (hope_segment_downsampled_staged); see segment_cloud_sharded.  Every step is bit-identical to the single-process path."""
 import numpy as np
 
 
@@ -73,11 +74,23 @@ def _ptr(t):
     return t.data_ptr(), t.is_cuda
 
 
+def _all_gather_rows(mine, sizes, dist):
+    """All-gather of row blocks of different lengths (padded to the longest), concatenated in rank order."""
+    import torch
+    pad = max(max(sizes), 1)
+    buf = torch.zeros((pad,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
+    buf[:mine.shape[0]] = mine
+    parts = [torch.empty_like(buf) for _ in sizes]
+    dist.all_gather(parts, buf)
+    return torch.cat([p[:s] for p, s in zip(parts, sizes)]).contiguous()
+
+
 def segment_cloud_sharded(ctx, xyz_local, dist, apply_filter_transform=False):
     """xyz_local: this rank's contiguous share of the cloud, float32 torch tensor [n, 3] (CPU with
     gloo, cuda with nccl = RCCL).  Ranks hold the points in rank order (rank 0 the lowest indices).
-    Afterwards `ctx` of EVERY rank holds the result of the whole cloud (A6..A12 run replicated on
-    the gathered down-sampled cloud), exactly as if one process had called segment_cloud on it.
+    Afterwards `ctx` of EVERY rank holds the result of the whole cloud (A6 and A8 shared by z band,
+    the rest replicated on the gathered down-sampled cloud), exactly as if one process had called
+    segment_cloud on it.
     Returns a dict of the exchanged sizes."""
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -127,10 +140,30 @@ def segment_cloud_sharded(ctx, xyz_local, dist, apply_filter_transform=False):
     parts = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(parts, buf)
     vox_all = torch.cat([p[:s] for p, s in zip(parts, sizes_l)]).contiguous()
-    # 5. A6..A12 on the whole down-sampled cloud
-    if vox_all.shape[0] == 0:
+    # 5. A6..A12 on the whole down-sampled cloud; the two neighbour searches (A6, A8) are shared by z band:
+    #    every rank holds all points, so its own band (a contiguous index range) needs no halo
+    n_vox = int(vox_all.shape[0])
+    if n_vox == 0:
         ctx.segment_cloud(np.zeros((0, 3), np.float32))
+        return {"n_raw_total": n_raw_total, "n_vox": 0, "sent": send_l, "received": recv_l, "bands": owner}
+    if world == 1:
+        ctx.segment_downsampled(vox_all.data_ptr(), n_vox, 12, vox_all.is_cuda, gbbox, n_raw_total)
+        return {"n_raw_total": n_raw_total, "n_vox": n_vox, "sent": send_l, "received": recv_l, "bands": owner}
+    first, count = sum(sizes_l[:rank]), sizes_l[rank]
+    args = (vox_all.data_ptr(), n_vox, 12, vox_all.is_cuda, gbbox, n_raw_total, first, count)
+    ctx.segment_downsampled_staged(*args, stop_after=1)
+    normals_all = _all_gather_rows(torch.from_numpy(ctx.normals(0)[first:first + count]).to(dev), sizes_l, dist)
+    ctx.segment_downsampled_staged(*args, normals_ptr=normals_all.data_ptr(), stop_after=2)
+    fit_idx = ctx.fit_indices(0)
+    lo, hi = (int(v) for v in np.searchsorted(fit_idx, [first, first + count]))
+    fit_sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+    fit_sizes[rank] = hi - lo
+    dist.all_reduce(fit_sizes, op=dist.ReduceOp.SUM)
+    fit_sizes_l = [int(v) for v in fit_sizes.cpu().tolist()]
+    if sum(fit_sizes_l) == 0:
+        knn_all = torch.zeros((1, ctx.cfg.knn), dtype=torch.int32, device=dev)
     else:
-        ctx.segment_downsampled(vox_all.data_ptr(), vox_all.shape[0], 12, vox_all.is_cuda, gbbox, n_raw_total)
-    return {"n_raw_total": n_raw_total, "n_vox": int(vox_all.shape[0]), "sent": send_l, "received": recv_l,
-            "bands": owner}
+        knn_all = _all_gather_rows(torch.from_numpy(ctx.knn(0)[lo:hi]).to(dev), fit_sizes_l, dist)
+    ctx.segment_downsampled_staged(*args, normals_ptr=normals_all.data_ptr(), knn_ptr=knn_all.data_ptr(), stop_after=0)
+    return {"n_raw_total": n_raw_total, "n_vox": n_vox, "n_fit": sum(fit_sizes_l), "sent": send_l, "received": recv_l,
+            "bands": owner, "own_vox": sizes_l, "own_fit": fit_sizes_l}

@@ -210,7 +210,8 @@ HOPE_API int hope_get_upon_cluster(hope_ctx* ctx, int cluster, float* xyz, int32
  *   5. hope_downsample_cloud_bbox  A5 on the received points with the global grid; the band
  *                               owners' outputs concatenated in rank order are the VoxelGrid
  *                               output of the whole cloud (hope_get_downsampled; all-gather)
- *   6. hope_segment_downsampled A6..A12 on the gathered down-sampled cloud                      */
+ *   6. hope_segment_downsampled A6..A12 on the gathered down-sampled cloud (or its staged form
+ *                               below, which shares A6 and A8 between the ranks)                 */
 HOPE_API int hope_grid_from_bbox(hope_ctx* ctx, const float bbox_min_max[6], int32_t min_b[3],
                                  int32_t div_b[3]);
 HOPE_API int hope_shard_bbox(hope_ctx* ctx, const void* xyz, size_t n, size_t stride_bytes,
@@ -230,6 +231,23 @@ HOPE_API int hope_downsample_cloud_bbox(hope_ctx* ctx, const void* xyz, size_t n
 HOPE_API int hope_segment_downsampled(hope_ctx* ctx, const void* vox_xyz, size_t n_vox,
                                       size_t stride_bytes, int on_device,
                                       const float bbox_min_max[6], int64_t n_raw_total);
+/* Step 6 with the two neighbour searches (A6 normals, A8 k-NN: most of its time) shared between
+ * the ranks by z band; every rank holds the whole down-sampled cloud, so no halo is needed.  Three
+ * calls with the same cloud, the all-gathers between them:
+ *   a. normals_all = NULL, knn_all = NULL, stop_after = 1: A6 for the down-sampled points
+ *      [own_first, own_first + own_count) only (hope_get_normals: rows of that range are valid);
+ *      all-gather the rows in rank order -> normals of every point (n_vox x 4 floats)
+ *   b. normals_all given, knn_all = NULL, stop_after = 2: A7 on all points (hope_get_fit_indices, the
+ *      same on every rank), A8 for the fit points whose down-sampled index lies in the own range
+ *      (hope_get_knn: those rows are valid); all-gather -> k-NN rows of every fit point (n_fit x knn)
+ *   c. both given, stop_after = 0: A7, A9..A12; the result is that of hope_segment_downsampled.
+ * normals_all / knn_all follow on_device like the cloud. */
+HOPE_API int hope_segment_downsampled_staged(hope_ctx* ctx, const void* vox_xyz, size_t n_vox,
+                                             size_t stride_bytes, int on_device,
+                                             const float bbox_min_max[6], int64_t n_raw_total,
+                                             int64_t own_first, int64_t own_count,
+                                             const float* normals_all, const int32_t* knn_all,
+                                             int stop_after);
 
 /* ---- instrumentation (HIP library only; no counterpart in the reference) ------------- */
 /* Per-stage device time measured with HIP events on the ctx stream, accumulated over the

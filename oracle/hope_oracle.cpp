@@ -1155,6 +1155,40 @@ ORACLE_API int hope_oracle_segment_downsampled(hope_ctx* ctx, const void* vox, s
   return oracle_cloud_staged(ctx, vox, n_vox, stride, bbox, 0, 1, n_raw_total);
 }
 
+// The checker's form of the staged call: it computes the whole result itself (own range and
+// stop_after need nothing special: every accessor is valid afterwards) and CHECKS the arrays the
+// ranks have gathered against its own, so a misplaced or stale piece fails the call.
+ORACLE_API int hope_oracle_segment_downsampled_staged(hope_ctx* ctx, const void* vox, size_t n_vox, size_t stride, int,
+                                                      const float bbox[6], int64_t n_raw_total, int64_t own_first,
+                                                      int64_t own_count, const float* normals_all,
+                                                      const int32_t* knn_all, int stop_after)
+{
+  if (!ctx || !bbox || own_first < 0 || own_count < 0 || (size_t)(own_first + own_count) > n_vox || stop_after < 0 ||
+      stop_after > 2)
+    return HOPE_E_INVALID;
+  const int st = oracle_cloud_staged(ctx, vox, n_vox, stride, bbox, 0, 1, n_raw_total);
+  if (st < 0 || ctx->frames.empty()) return st;
+  const Frame& f = ctx->frames[0];
+  if (normals_all) {
+    for (size_t i = 0; i < f.nx.size(); ++i) {
+      const float mine[4] = {f.nx[i], f.ny[i], f.nz[i], f.curv[i]};
+      if (std::memcmp(mine, normals_all + 4 * i, sizeof(mine)) != 0) {
+        ctx->err = "staged call: gathered normals differ from the oracle's at point " + std::to_string(i);
+        return HOPE_E_INVALID;
+      }
+    }
+  }
+  if (knn_all) {
+    for (size_t i = 0; i < f.knn.size(); ++i) {
+      if (f.knn[i] != knn_all[i]) {
+        ctx->err = "staged call: gathered k-NN rows differ from the oracle's at entry " + std::to_string(i);
+        return HOPE_E_INVALID;
+      }
+    }
+  }
+  return st;
+}
+
 #define GET_FRAME(ctx, frame)                                            \
   if (!(ctx)) return HOPE_E_INVALID;                                     \
   if ((frame) < 0 || (frame) >= (int)(ctx)->frames.size()) return HOPE_E_RANGE; \

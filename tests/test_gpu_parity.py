@@ -307,6 +307,27 @@ def test_staged_cloud_entry_points(hip_lib, oracle_lib):
         assert vox_all.tobytes() == ref.downsampled(0).tobytes()
         c.segment_downsampled(vox_all.ctypes.data, vox_all.shape[0], 12, False, gb, n_raw)
         assert summary(c, 0) == summary(ref, 0)
+        # the same last step with A6 and A8 shared by z band (hope_segment_downsampled_staged)
+        n_vox = vox_all.shape[0]
+        args = (vox_all.ctypes.data, n_vox, 12, False, gb, n_raw)
+        firsts = np.concatenate([[0], np.cumsum([v.shape[0] for v in vox])]).astype(np.int64)
+        nrm = []
+        for r in range(world):
+            c.segment_downsampled_staged(*args, firsts[r], firsts[r + 1] - firsts[r], stop_after=1)
+            nrm.append(c.normals(0)[firsts[r]:firsts[r + 1]].copy())
+        normals_all = np.ascontiguousarray(np.concatenate(nrm))
+        assert normals_all.tobytes() == ref.normals(0).tobytes()
+        rows = []
+        for r in range(world):
+            c.segment_downsampled_staged(*args, firsts[r], firsts[r + 1] - firsts[r],
+                                         normals_ptr=normals_all.ctypes.data, stop_after=2)
+            fit_idx = c.fit_indices(0)
+            lo, hi = np.searchsorted(fit_idx, [firsts[r], firsts[r + 1]])
+            rows.append(c.knn(0)[lo:hi].copy())
+        knn_all = np.ascontiguousarray(np.concatenate(rows))
+        assert np.array_equal(knn_all, ref.knn(0))
+        c.segment_downsampled_staged(*args, 0, n_vox, normals_ptr=normals_all.ctypes.data, knn_ptr=knn_all.ctypes.data)
+        assert summary(c, 0) == summary(ref, 0)
     # (n_in differs by construction: the last stage's input is the down-sampled cloud)
     assert np.array_equal(ref.labels(0), g.labels(0)) and np.array_equal(ref.knn(0), g.knn(0))
     assert ref.clusters(0).tobytes() == g.clusters(0).tobytes()
