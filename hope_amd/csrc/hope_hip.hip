@@ -1714,6 +1714,40 @@ HOPE_API int hope_get_normals(hope_ctx* c, int frame, float* nxyzc)
   return copy_out(c, nxyzc, c->d_normals + F.vox_start, sizeof(float4) * (size_t)F.n_vox);
 }
 
+HOPE_API int hope_get_normals_rows(hope_ctx* c, int frame, int64_t first, int64_t count, float* out, int out_on_device)
+{
+  GET_FRAME(c, frame);
+  if (first < 0 || count < 0 || first + count > F.n_vox) return HOPE_E_RANGE;
+  if (count == 0) return HOPE_OK;
+  if (!out || !c->d_normals) return HOPE_E_INVALID;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  HIPCHK(hipMemcpyAsync(out, c->d_normals + F.vox_start + first, sizeof(float4) * (size_t)count,
+                        out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return HOPE_OK;
+}
+
+HOPE_API int hope_get_knn_rows(hope_ctx* c, int frame, int64_t first, int64_t count, int32_t* out, int out_on_device)
+{
+  GET_FRAME(c, frame);
+  if (first < 0 || count < 0 || first + count > F.n_fit) return HOPE_E_RANGE;
+  if (count == 0) return HOPE_OK;
+  if (!out || !c->d_knn) return HOPE_E_INVALID;
+  if (out_on_device && F.fit_start != 0) {
+    c->err = "hope_get_knn_rows: device output is for single-frame calls";
+    return HOPE_E_INVALID;
+  }
+  const int K = c->cfg.knn;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  HIPCHK(hipMemcpyAsync(out, c->d_knn + ((size_t)F.fit_start + first) * K, sizeof(int32_t) * (size_t)count * K,
+                        out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (!out_on_device && F.fit_start != 0)
+    for (size_t i = 0; i < (size_t)count * K; ++i)
+      if (out[i] >= 0) out[i] -= F.fit_start;
+  return HOPE_OK;
+}
+
 HOPE_API int hope_get_fit_indices(hope_ctx* c, int frame, int32_t* idx)
 {
   GET_FRAME(c, frame);

@@ -152,7 +152,9 @@ def segment_cloud_sharded(ctx, xyz_local, dist, apply_filter_transform=False):
     first, count = sum(sizes_l[:rank]), sizes_l[rank]
     args = (vox_all.data_ptr(), n_vox, 12, vox_all.is_cuda, gbbox, n_raw_total, first, count)
     ctx.segment_downsampled_staged(*args, stop_after=1)
-    normals_all = _all_gather_rows(torch.from_numpy(ctx.normals(0)[first:first + count]).to(dev), sizes_l, dist)
+    own_n = torch.empty((count, 4), dtype=torch.float32, device=dev)   # written by the library, host or device
+    ctx.normals_rows(first, count, out_ptr=own_n.data_ptr(), out_on_device=own_n.is_cuda)
+    normals_all = _all_gather_rows(own_n, sizes_l, dist)
     ctx.segment_downsampled_staged(*args, normals_ptr=normals_all.data_ptr(), stop_after=2)
     fit_idx = ctx.fit_indices(0)
     lo, hi = (int(v) for v in np.searchsorted(fit_idx, [first, first + count]))
@@ -163,7 +165,9 @@ def segment_cloud_sharded(ctx, xyz_local, dist, apply_filter_transform=False):
     if sum(fit_sizes_l) == 0:
         knn_all = torch.zeros((1, ctx.cfg.knn), dtype=torch.int32, device=dev)
     else:
-        knn_all = _all_gather_rows(torch.from_numpy(ctx.knn(0)[lo:hi]).to(dev), fit_sizes_l, dist)
+        own_k = torch.empty((hi - lo, ctx.cfg.knn), dtype=torch.int32, device=dev)
+        ctx.knn_rows(lo, hi - lo, out_ptr=own_k.data_ptr(), out_on_device=own_k.is_cuda)
+        knn_all = _all_gather_rows(own_k, fit_sizes_l, dist)
     ctx.segment_downsampled_staged(*args, normals_ptr=normals_all.data_ptr(), knn_ptr=knn_all.data_ptr(), stop_after=0)
     return {"n_raw_total": n_raw_total, "n_vox": n_vox, "n_fit": sum(fit_sizes_l), "sent": send_l, "received": recv_l,
             "bands": owner, "own_vox": sizes_l, "own_fit": fit_sizes_l}

@@ -242,6 +242,13 @@ HOPE_API int hope_segment_downsampled(hope_ctx* ctx, const void* vox_xyz, size_t
  *      (hope_get_knn: those rows are valid); all-gather -> k-NN rows of every fit point (n_fit x knn)
  *   c. both given, stop_after = 0: A7, A9..A12; the result is that of hope_segment_downsampled.
  * normals_all / knn_all follow on_device like the cloud. */
+/* Rows [first, first + count) of hope_get_normals / hope_get_knn of a frame, into host memory or
+ * (out_on_device != 0; k-NN rows: single-frame calls only) straight into device memory: what a rank
+ * contributes to the all-gathers of the staged call below. */
+HOPE_API int hope_get_normals_rows(hope_ctx* ctx, int frame, int64_t first, int64_t count,
+                                   float* nxyzc, int out_on_device);
+HOPE_API int hope_get_knn_rows(hope_ctx* ctx, int frame, int64_t first, int64_t count,
+                               int32_t* nbr, int out_on_device);
 HOPE_API int hope_segment_downsampled_staged(hope_ctx* ctx, const void* vox_xyz, size_t n_vox,
                                              size_t stride_bytes, int on_device,
                                              const float bbox_min_max[6], int64_t n_raw_total,

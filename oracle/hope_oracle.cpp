@@ -1369,6 +1369,30 @@ ORACLE_API int hope_oracle_get_normals(hope_ctx* ctx, int frame, float* o)
   return HOPE_OK;
 }
 
+ORACLE_API int hope_oracle_get_normals_rows(hope_ctx* ctx, int frame, int64_t first, int64_t count, float* o, int)
+{
+  GET_FRAME(ctx, frame);
+  if (first < 0 || count < 0 || (size_t)(first + count) > f.nx.size()) return HOPE_E_RANGE;
+  if (count > 0 && !o) return HOPE_E_INVALID;
+  for (int64_t i = 0; i < count; ++i) {
+    o[4 * i] = f.nx[first + i];
+    o[4 * i + 1] = f.ny[first + i];
+    o[4 * i + 2] = f.nz[first + i];
+    o[4 * i + 3] = f.curv[first + i];
+  }
+  return HOPE_OK;
+}
+
+ORACLE_API int hope_oracle_get_knn_rows(hope_ctx* ctx, int frame, int64_t first, int64_t count, int32_t* o, int)
+{
+  GET_FRAME(ctx, frame);
+  const int64_t K = ctx->cfg.knn;
+  if (first < 0 || count < 0 || (size_t)((first + count) * K) > f.knn.size()) return HOPE_E_RANGE;
+  if (count > 0 && !o) return HOPE_E_INVALID;
+  std::copy(f.knn.begin() + first * K, f.knn.begin() + (first + count) * K, o);
+  return HOPE_OK;
+}
+
 ORACLE_API int hope_oracle_get_fit_indices(hope_ctx* ctx, int frame, int32_t* idx)
 {
   GET_FRAME(ctx, frame);

@@ -259,6 +259,32 @@ def test_knn_leftovers_through_the_coarse_index(hip_lib, oracle_lib, monkeypatch
     assert_frame_equal(o, g_fine, 0)
 
 
+def test_row_accessors_into_device_memory(hip_lib, oracle_lib):
+    """hope_get_normals_rows / hope_get_knn_rows write a row range to host memory or straight into device
+    memory (what a rank contributes to the all-gathers of the staged multi-GPU call)."""
+    import torch
+    from hope_amd import synth
+    xyz = synth.make_multilevel_cloud(150000, first_index=5, device="cpu").numpy()
+    g, o = both(hip_lib, oracle_lib)
+    for c in (g, o):
+        assert c.segment_cloud(xyz) == 0
+    n_vox, n_fit = int(g.counts(0).n_vox), int(g.counts(0).n_fit)
+    a, b = n_vox // 3, n_vox - 7
+    fa, fb = n_fit // 4, n_fit - 3
+    ref_n, ref_k = o.normals(0), o.knn(0)
+    assert g.normals_rows(a, b - a).tobytes() == ref_n[a:b].tobytes()
+    assert np.array_equal(g.knn_rows(fa, fb - fa), ref_k[fa:fb])
+    dn = torch.empty((b - a, 4), dtype=torch.float32, device="cuda")
+    dk = torch.empty((fb - fa, g.cfg.knn), dtype=torch.int32, device="cuda")
+    g.normals_rows(a, b - a, out_ptr=dn.data_ptr(), out_on_device=True)
+    g.knn_rows(fa, fb - fa, out_ptr=dk.data_ptr(), out_on_device=True)
+    torch.cuda.synchronize()
+    assert dn.cpu().numpy().tobytes() == ref_n[a:b].tobytes()
+    assert np.array_equal(dk.cpu().numpy(), ref_k[fa:fb])
+    assert o.normals_rows(a, b - a).tobytes() == ref_n[a:b].tobytes()
+    assert np.array_equal(o.knn_rows(fa, fb - fa), ref_k[fa:fb])
+
+
 def test_staged_cloud_entry_points(hip_lib, oracle_lib):
     """The device stages behind hope_amd.sharding.segment_cloud_sharded, driven here for three
     'ranks' one after the other in one process (the exchanges become numpy concatenations): the
