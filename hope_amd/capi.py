@@ -73,7 +73,7 @@ ABI_SYMBOLS = [
     "get_knn", "get_labels", "get_clusters", "get_cluster_indices", "get_max_plane",
     "last_timing", "grid_from_bbox", "shard_bbox", "shard_z_histogram", "shard_route",
     "downsample_cloud_bbox", "segment_downsampled", "segment_downsampled_staged",
-    "get_normals_rows", "get_knn_rows",
+    "get_normals_rows", "get_knn_rows", "get_downsampled_to",
     "clusters_upon_plane", "get_upon_cluster_sizes", "get_upon_cluster",
 ]
 
@@ -122,6 +122,7 @@ class HopeLib:
             "shard_route": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, i32, i32, vp, vp, i32, i32, vp, i32, vp]),
             "downsample_cloud_bbox": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, i32, vp]),
             "segment_downsampled": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, i32, vp, C.c_int64]),
+            "get_downsampled_to": (C.c_int, [vp, i32, vp, i32]),
             "get_normals_rows": (C.c_int, [vp, i32, C.c_int64, C.c_int64, vp, i32]),
             "get_knn_rows": (C.c_int, [vp, i32, C.c_int64, C.c_int64, vp, i32]),
             "segment_downsampled_staged": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, i32, vp, C.c_int64, C.c_int64,
@@ -319,6 +320,10 @@ class HopeContext:
         return self._check(self.lib.fn["segment_downsampled_staged"](
             self._h, ptr, n_vox, stride_bytes, int(on_device), b.ctypes.data, int(n_raw_total), int(own_first),
             int(own_count), normals_ptr, knn_ptr, int(stop_after)), "segment_downsampled_staged")
+
+    def downsampled_to(self, out_ptr, out_on_device, frame=0):
+        """The down-sampled cloud (n_vox x 3 floats) to out_ptr, host or device."""
+        self._check(self.lib.fn["get_downsampled_to"](self._h, frame, out_ptr, int(out_on_device)), "get_downsampled_to")
 
     def normals_rows(self, first, count, frame=0, out_ptr=None, out_on_device=False):
         """Rows [first, first+count) of the normals: into a new numpy array, or to out_ptr (host or device)."""

@@ -1714,6 +1714,19 @@ HOPE_API int hope_get_normals(hope_ctx* c, int frame, float* nxyzc)
   return copy_out(c, nxyzc, c->d_normals + F.vox_start, sizeof(float4) * (size_t)F.n_vox);
 }
 
+HOPE_API int hope_get_downsampled_to(hope_ctx* c, int frame, float* xyz, int out_on_device)
+{
+  if (!out_on_device) return hope_get_downsampled(c, frame, xyz);
+  GET_FRAME(c, frame);
+  if (F.n_vox == 0) return HOPE_OK;
+  if (!xyz) return HOPE_E_INVALID;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  hipLaunchKernelGGL(k_pack_xyz, dim3(nblk((size_t)F.n_vox)), dim3(kBlock), 0, c->stream, c->d_vox + F.vox_start,
+                     (unsigned)F.n_vox, xyz);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return HOPE_OK;
+}
+
 HOPE_API int hope_get_normals_rows(hope_ctx* c, int frame, int64_t first, int64_t count, float* out, int out_on_device)
 {
   GET_FRAME(c, frame);

@@ -2295,6 +2295,17 @@ k_adopt_downsampled(Src src, FrameInfo* fi, float4* vox, int* vox_frame)
   vox_frame[i] = 0;
 }
 
+// x, y, z of the down-sampled points, packed (hope_get_downsampled_to)
+__global__ void __launch_bounds__(kBlock) k_pack_xyz(const float4* vox, unsigned n, float* xyz)
+{
+  const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = vox[i];
+  xyz[3 * (size_t)i] = p.x;
+  xyz[3 * (size_t)i + 1] = p.y;
+  xyz[3 * (size_t)i + 2] = p.z;
+}
+
 // ---- on-demand export of the transformed cloud (hope_get_transformed) -------------------
 template <class Src>
 __global__ void __launch_bounds__(kBlock)

@@ -129,7 +129,9 @@ def segment_cloud_sharded(ctx, xyz_local, dist, apply_filter_transform=False):
                            [3 * v for v in send_l])
     # 4. VoxelGrid on the band with the global grid; gather the down-sampled cloud
     ctx.downsample_cloud_bbox(mine.data_ptr(), sum(recv_l), 12, mine.is_cuda, gbbox)
-    vox_local = torch.from_numpy(ctx.downsampled(0)).to(dev)
+    vox_local = torch.empty((int(ctx.counts(0).n_vox), 3), dtype=torch.float32, device=dev)
+    if vox_local.shape[0]:
+        ctx.downsampled_to(vox_local.data_ptr(), vox_local.is_cuda)
     sizes = torch.zeros(world, dtype=torch.int64, device=dev)
     sizes[rank] = vox_local.shape[0]
     dist.all_reduce(sizes, op=dist.ReduceOp.SUM)

@@ -245,6 +245,9 @@ HOPE_API int hope_segment_downsampled(hope_ctx* ctx, const void* vox_xyz, size_t
 /* Rows [first, first + count) of hope_get_normals / hope_get_knn of a frame, into host memory or
  * (out_on_device != 0; k-NN rows: single-frame calls only) straight into device memory: what a rank
  * contributes to the all-gathers of the staged call below. */
+/* hope_get_downsampled into host or (out_on_device != 0) device memory: a rank's band of the VoxelGrid
+ * output, as it goes into the all-gather */
+HOPE_API int hope_get_downsampled_to(hope_ctx* ctx, int frame, float* xyz, int out_on_device);
 HOPE_API int hope_get_normals_rows(hope_ctx* ctx, int frame, int64_t first, int64_t count,
                                    float* nxyzc, int out_on_device);
 HOPE_API int hope_get_knn_rows(hope_ctx* ctx, int frame, int64_t first, int64_t count,

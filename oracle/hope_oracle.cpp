@@ -1369,6 +1369,11 @@ ORACLE_API int hope_oracle_get_normals(hope_ctx* ctx, int frame, float* o)
   return HOPE_OK;
 }
 
+ORACLE_API int hope_oracle_get_downsampled_to(hope_ctx* ctx, int frame, float* xyz, int)
+{
+  return hope_oracle_get_downsampled(ctx, frame, xyz);
+}
+
 ORACLE_API int hope_oracle_get_normals_rows(hope_ctx* ctx, int frame, int64_t first, int64_t count, float* o, int)
 {
   GET_FRAME(ctx, frame);
