@@ -893,6 +893,8 @@ int check_fast_div(hope_ctx* c, const DepthSrc& src)
   return HOPE_OK;
 }
 
+constexpr int kRetryPerPoint = -1000;  // internal: never leaves the library
+
 template <class Src>
 int run_pipeline(hope_ctx* c, const Src& src, size_t n_per_frame)
 {
@@ -950,7 +952,8 @@ int run_pipeline(hope_ctx* c, const Src& src, size_t n_per_frame)
   }
   {
     size_t pm = prof_mark(c);
-    hipLaunchKernelGGL(k_frame_grid, dim3(1), dim3(1024), 0, s, d_fi, F, c->inv_xy, c->inv_z, c->d_glob);
+    hipLaunchKernelGGL(k_frame_grid, dim3(1), dim3(1024), 0, s, d_fi, F, c->inv_xy, c->inv_z, (unsigned)n_per_frame,
+                       c->d_glob);
     prof_close(c, ST_GRID, pm, (double)sizeof(FrameInfo) * F);
     pm = prof_mark(c);
     st = scan_groups(c, src, n_per_frame);
@@ -959,10 +962,22 @@ int run_pipeline(hope_ctx* c, const Src& src, size_t n_per_frame)
   }
   st = sync_globals(c);
   if (st != HOPE_OK) return st;
-  if (c->h_glob->any_overflow) {
-    c->err = "VoxelGrid leaf size too small for the input extent (more than INT_MAX cells); "
-             "PCL would pass the cloud through unfiltered, which this library does not support";
+  if (c->h_glob->any_overflow & ~1u) {
+    c->err = (c->h_glob->any_overflow & 2u)
+                 ? "leaf size too small for the input extent: more than 2^30 columns of th_xy in a frame, or cell "
+                   "coordinates beyond 2^30 (PCL would pass the cloud through; no column index of that size is built)"
+                 : "the column tables of this batch exceed 2^31 entries: pass fewer frames per call";
     return HOPE_E_RANGE;
+  }
+  if (c->h_glob->any_overflow & 1u) {
+    // a frame with more than INT_MAX cells: PCL's VoxelGrid copies its input through.  Here every
+    // point of such a frame becomes a voxel of its own in the per-point voxel stage; a depth batch on
+    // the group path starts again on that stage (kRetryPerPoint: see hope_segment_depth_u16)
+    if (c->forced_bbox || c->input_is_downsampled) {
+      c->err = "staged cloud call: VoxelGrid pass-through (more than INT_MAX cells) is not supported across ranks";
+      return HOPE_E_RANGE;
+    }
+    if (use_groups(c, src)) return kRetryPerPoint;
   }
 
   // ---- A5 voxel grid ------------------------------------------------------------------
@@ -1173,7 +1188,16 @@ HOPE_API int hope_segment_depth_u16(hope_ctx* c, const uint16_t* depth, int w, i
   c->dsrc = src;
   int st = check_fast_div(c, src);
   if (st != HOPE_OK) return st;
-  return run_pipeline(c, src, ppf);
+  const std::vector<size_t> mark = c->arena.mark();
+  st = run_pipeline(c, src, ppf);
+  if (st == kRetryPerPoint) {
+    const int knob = c->pixel_sort;
+    c->pixel_sort = 1;
+    c->arena.rollback(mark);
+    st = run_pipeline(c, src, ppf);
+    c->pixel_sort = knob;
+  }
+  return st;
 }
 
 HOPE_API int hope_segment_cloud_xyz(hope_ctx* c, const void* xyz, size_t n, size_t stride, int apply, int on_device)
@@ -1260,7 +1284,7 @@ int shard_frame(hope_ctx* c, const float* bbox)
     // k_frame_grid only builds a grid for a frame with points
     const int one = 1;
     HIPCHK(hipMemcpyAsync(&d_fi->n_raw, &one, sizeof(int), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_frame_grid, dim3(1), dim3(1024), 0, c->stream, d_fi, 1, c->inv_xy, c->inv_z, c->d_glob);
+    hipLaunchKernelGGL(k_frame_grid, dim3(1), dim3(1024), 0, c->stream, d_fi, 1, c->inv_xy, c->inv_z, 0u, c->d_glob);
   }
   return HOPE_OK;
 }
@@ -1476,11 +1500,11 @@ HOPE_API int hope_frame_counts(hope_ctx* c, int frame, hope_counts* out)
   out->n_segments = F.n_segments;
   out->n_clusters = F.n_clusters;
   out->n_planes = c->h_nplanes[frame];
-  for (int d = 0; d < 3; ++d) {
-    out->grid[d] = F.div_b[d];
-    out->min_b[d] = F.min_b[d];
+  for (int d = 0; d < 3; ++d) {  // (a pass-through frame has no VoxelGrid grid: div_b / min_b only index columns)
+    out->grid[d] = F.overflow ? 0 : F.div_b[d];
+    out->min_b[d] = F.overflow ? 0 : F.min_b[d];
   }
-  out->vox_passthrough = 0;
+  out->vox_passthrough = F.overflow ? 1 : 0;
   out->status = F.status;
   return HOPE_OK;
 }

@@ -195,15 +195,17 @@ __global__ void __launch_bounds__(kBlock) k_bbox(Src src, FrameInfo* fi)
 }
 
 // ---- K2: VoxelGrid grid set-up per frame (PCL 1.8.1 voxel_grid.hpp applyFilter) -------
-__global__ void __launch_bounds__(1024) k_frame_grid(FrameInfo* fi, int n_frames, float inv_xy, float inv_z, Globals* g)
+__global__ void __launch_bounds__(1024) k_frame_grid(FrameInfo* fi, int n_frames, float inv_xy, float inv_z, unsigned n_per_frame, Globals* g)
 {
   // one 1024-thread block: per-frame grid set-up in parallel, then a block-wide exclusive
   // scan of the per-frame column-table sizes
   __shared__ unsigned s_scan[1024];
   __shared__ unsigned long long s_max_cells;
+  __shared__ unsigned long long s_all_cols;
   __shared__ unsigned s_max_dz, s_any_over, s_carry, s_carry2, s_max_tiles;
   const int tid = threadIdx.x;
   if (tid == 0) {
+    s_all_cols = 0;
     s_max_cells = 1;
     s_max_dz = 1;
     s_any_over = 0;
@@ -226,24 +228,44 @@ __global__ void __launch_bounds__(1024) k_frame_grid(FrameInfo* fi, int n_frames
       if (F.n_raw > 0) {
         const float inv[3] = {inv_xy, inv_xy, inv_z};
         long long dxyz = 1;
-        float maxabs = 0.f;
+        float maxabs = 0.f, maxabs3 = 0.f;
         for (int d = 0; d < 3; ++d) {
           const float mn = ord2f(F.bb_min[d]), mx = ord2f(F.bb_max[d]);
           dxyz *= (long long)((mx - mn) * inv[d]) + 1;
-          min_b[d] = (int)floorf(mn * inv[d]);
-          const int max_b = (int)floorf(mx * inv[d]);
-          div_b[d] = max_b - min_b[d] + 1;
-          if (d < 2) maxabs = fmaxf(maxabs, fmaxf(fabsf(mn), fabsf(mx)) * inv[d]);
+          const float m = fmaxf(fabsf(mn), fabsf(mx)) * inv[d];
+          maxabs3 = fmaxf(maxabs3, m);
+          if (d < 2) maxabs = fmaxf(maxabs, m);
         }
-        if (dxyz > 2147483647LL) {
+        // (a cell coordinate beyond 2^30 has no int representation worth computing: PCL's own cast
+        // would be undefined there, and such a frame cannot be indexed by columns either)
+        const bool indexable = maxabs3 < 1073741824.f;
+        if (indexable) {
+          for (int d = 0; d < 3; ++d) {
+            min_b[d] = (int)floorf(ord2f(F.bb_min[d]) * inv[d]);
+            div_b[d] = (int)floorf(ord2f(F.bb_max[d]) * inv[d]) - min_b[d] + 1;
+          }
+        }
+        const long long cols = (long long)div_b[0] * div_b[1];
+        if (!indexable || (dxyz > 2147483647LL && cols > 0x3fffffffLL)) {
+          // no column table of a sane size: the call is refused
           overflow = 1;
-          atomicOr(&s_any_over, 1u);
+          atomicOr(&s_any_over, 2u);
           for (int d = 0; d < 3; ++d) min_b[d] = div_b[d] = 0;
         } else {
-          cells = (long long)div_b[0] * div_b[1] * div_b[2];
+          if (dxyz > 2147483647LL) {
+            // "Leaf size is too small for the input dataset": PCL copies the input through
+            // (voxel_grid.hpp applyFilter).  Every surviving point becomes a voxel of its own (key =
+            // its index in the frame); min_b / div_b only shape the column index of A6 / A8
+            overflow = 1;
+            atomicOr(&s_any_over, 1u);
+            cells = 0;
+            atomicMax(&s_max_cells, (unsigned long long)n_per_frame);
+          } else {
+            cells = (long long)div_b[0] * div_b[1] * div_b[2];
+            atomicMax(&s_max_cells, (unsigned long long)cells);
+          }
           // |fl(x*inv) - x*inv| <= 2^-24 * |x*inv|; two such errors enter a column difference
           slack = maxabs * 2.4e-7f + 1e-6f;
-          atomicMax(&s_max_cells, (unsigned long long)cells);
           atomicMax(&s_max_dz, (unsigned)div_b[2]);
           ncols = (unsigned)(div_b[0] * div_b[1]) + 1u;
           nccols = (unsigned)(((div_b[0] + kCoarse - 1) / kCoarse) * ((div_b[1] + kCoarse - 1) / kCoarse)) + 1u;
@@ -258,6 +280,7 @@ __global__ void __launch_bounds__(1024) k_frame_grid(FrameInfo* fi, int n_frames
       F.cells = cells;
       F.slack = slack;
     }
+    if (ncols > 1u) atomicAdd(&s_all_cols, (unsigned long long)ncols);
     // inclusive Hillis-Steele scan of ncols over the chunk
     s_scan[tid] = ncols;
     __syncthreads();
@@ -291,7 +314,7 @@ __global__ void __launch_bounds__(1024) k_frame_grid(FrameInfo* fi, int n_frames
     g->max_cells = s_max_cells;
     g->total_cols = s_carry;
     g->max_div_z = s_max_dz;
-    g->any_overflow = s_any_over;
+    g->any_overflow = s_any_over | (s_all_cols > 0x7fffffffull ? 4u : 0u);  // (col_off is an int)
     g->max_tiles = s_max_tiles;
     g->total_ccols = s_carry2;
   }
@@ -311,12 +334,13 @@ k_voxel_keys(Src src, const FrameInfo* fi, float inv_xy, float inv_z, int cell_b
   for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     float x, y, z;
     KeyT key = (KeyT)n_frames << cell_bits;  // sentinel: sorts behind every frame
-    if (!F.overflow && load_point(src, fi, frame, i, x, y, z)) {
+    if (load_point(src, fi, frame, i, x, y, z)) {
       const int i0 = (int)(floorf(x * inv_xy) - (float)F.min_b[0]);
       const int i1 = (int)(floorf(y * inv_xy) - (float)F.min_b[1]);
       const int i2 = (int)(floorf(z * inv_z) - (float)F.min_b[2]);
-      const int idx = i0 + i1 * F.div_b[0] + i2 * (F.div_b[0] * F.div_b[1]);
-      key = ((KeyT)frame << cell_bits) | (KeyT)(unsigned)idx;
+      // (pass-through frame, F.overflow: every point is a voxel of its own, in input order)
+      const unsigned idx = F.overflow ? i : (unsigned)(i0 + i1 * F.div_b[0] + i2 * (F.div_b[0] * F.div_b[1]));
+      key = ((KeyT)frame << cell_bits) | (KeyT)idx;
     }
     const size_t o = (size_t)frame * n + i;
     keys[o] = key;
@@ -417,11 +441,11 @@ k_voxel_keys_depth8(DepthSrc src, const FrameInfo* fi, float inv_xy, float inv_z
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       k[j] = sentinel;
-      if (!over && (p.valid & (1u << j))) {
+      if (p.valid & (1u << j)) {
         const int i0 = (int)(floorf(p.x[j] * inv_xy) - (float)mb0);
         const int i1 = (int)(floorf(p.y[j] * inv_xy) - (float)mb1);
         const int i2 = (int)(floorf(p.z[j] * inv_z) - (float)mb2);
-        k[j] = fbits | (KeyT)(unsigned)(i0 + i1 * d0 + i2 * d01);
+        k[j] = fbits | (KeyT)(over ? t * 8 + (unsigned)j : (unsigned)(i0 + i1 * d0 + i2 * d01));
       }
       v[j] = (uint32_t)(o + j);
     }
@@ -1104,7 +1128,12 @@ k_centroids_w(Src src, const FrameInfo* fi, const KeyT* unique, const uint32_t* 
   }
   if (live) {
     const float c = (float)my_cnt;
-    vox[v] = make_float4(sx / c, sy / c, sz / c, 0.f);
+    float4 out = make_float4(sx / c, sy / c, sz / c, 0.f);
+    if (fi[frame].overflow) {
+      // pass-through frame: the point itself (0.f + x would lose the sign of a -0.f)
+      load_point(src, fi, frame, vals_sorted[my_start] - (unsigned)((size_t)frame * n), out.x, out.y, out.z);
+    }
+    vox[v] = out;
     vox_frame[v] = frame;
   }
 }

@@ -365,7 +365,14 @@ struct TileWalker {
   {
     const float layers = fmaxf((zmax - zmin) / leaf_z + 1.f, 1.f);
     const float per_layer = fmaxf((float)count / layers, 1e-3f);
-    return (int)fminf(fmaxf(0.6f * (float)kTileCap / per_layer - 2.f * zhalo / leaf_z, 1.f), 65536.f);
+    return (int)fminf(fmaxf(0.6f * (float)kTileCap / per_layer - 2.f * zhalo / leaf_z, 1.f), 1.0e9f);
+  }
+
+  // after a slab that fitted: double the height for the next one if this one was sparse, or if it is
+  // so thin next to its z halo (a z grid far finer than the search radius) that doubling adds next to nothing
+  __device__ __forceinline__ bool grow(unsigned total, int h) const
+  {
+    return total * 4u <= (unsigned)kTileCap || (float)h * leaf_z * 8.f < zhalo;
   }
 
   __device__ __forceinline__ bool next(TileGeom& g)
@@ -397,7 +404,7 @@ struct TileWalker {
           unsigned count;
           if (!region_z_extent<WITH_FIT, HALO>(F, g, spt, col_first, S, zmin, zmax, count)) continue;
           z4 = fmaxf(zs8, zmin - 1.5f * leaf_z);
-          zend4 = ze8;
+          zend4 = fminf(ze8, zmax + 1.5f * leaf_z);
           h4 = slab_cells(count, zmin, zmax);
           in4walk = true;
         }
@@ -412,11 +419,15 @@ struct TileWalker {
           h4 = max(h4 / 2, 1);
           continue;
         }
+        // (a one-cell slab that does not fit -- raw, not down-sampled, points -- is served from the global
+        // arrays, which have no capacity: then the rest of the z range goes in the same step)
+        const float z1u = g.in_lds ? z1 : zend4;
         g.z0 = z4;
-        g.z1 = z1;
-        z4 = z1;
+        g.z1 = z1u;
+        z4 = z1u;
+        if (g.in_lds && grow(g.total, h4)) h4 = min(h4 * 2, 1 << 30);
         if (g.in_lds && g.total == 0) continue;
-        return true;  // (in_lds false here cannot happen; the caller then reads from the global arrays)
+        return true;  // (in_lds false: the caller reads from the global arrays)
       }
       if (in8) {
         if (!(z8 < zend8)) {
@@ -431,16 +442,19 @@ struct TileWalker {
             h8 = max(h8 / 2, 1);
             continue;
           }
+          // the 4x4 regions take over the rest of the quarter's z range, each with a slab height of its own
+          // (handing back one cell at a time would crawl through a dense stretch of a fine z grid)
           in4 = true;
           in4walk = false;
           b = 0;
           zs8 = z8;
-          ze8 = z1;
+          ze8 = zend8;
           continue;
         }
         g.z0 = z8;
         g.z1 = z1;
         z8 = z1;
+        if (grow(g.total, h8)) h8 = min(h8 * 2, 1 << 30);
         if (g.total == 0) continue;
         return true;
       }
@@ -505,14 +519,17 @@ __device__ __forceinline__ void for_each_interior(const FrameInfo& F, const Tile
       fn_lds(q, cqx, cqy);
     }
   } else {
-    const int w = g.x1 - g.x0;
-    for (int c = threadIdx.x; c < w * (g.y1 - g.y0); c += kBlock) {
+    // (several threads share a column when the region has fewer columns than the block has threads)
+    const int w = g.x1 - g.x0, ncol = w * (g.y1 - g.y0);
+    const int share = ncol < kBlock ? kBlock / max(ncol, 1) : 1;
+    for (int t = threadIdx.x; t < ncol * share; t += kBlock) {
+      const int c = t / share;
       const int cx = g.x0 + c % w, cy = g.y0 + c / w;
       const unsigned col = (unsigned)F.col_off + (unsigned)(cy * dx + cx);
       unsigned a = col_first[col];
       const unsigned b = col_first[col + 1];
       a = lower_bound_z_glob(spt, a, b, g.z0 - 2.5f * leaf_z);
-      for (unsigned e = a; e < b; ++e) {
+      for (unsigned e = a + (unsigned)(t % share); e < b; e += (unsigned)share) {
         const float4 q = spt[e];
         if (q.z >= g.z1 + 2.5f * leaf_z) break;
         if (q.z >= g.z0 && q.z < g.z1) fn_glob(q, cx, cy);

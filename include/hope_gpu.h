@@ -91,7 +91,8 @@ typedef struct hope_counts {
   int32_t n_planes;       /* clusters that passed normalAnalysis (+ RT height gate)  */
   int32_t grid[3];        /* VoxelGrid div_b (A5)                                    */
   int32_t min_b[3];       /* VoxelGrid min_b (A5)                                    */
-  int32_t vox_passthrough;/* 1 if PCL's "leaf size too small" rule copied the input  */
+  int32_t vox_passthrough;/* 1 if PCL's "leaf size too small" rule copied the input
+                             (more than INT_MAX cells: n_vox = n_raw, grid = min_b = 0) */
   int32_t status;         /* HOPE_OK / HOPE_EMPTY / HOPE_NO_NORMAL_FIT for this frame */
   int32_t reserved[3];
 } hope_counts;

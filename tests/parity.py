@@ -9,7 +9,7 @@ def bits(a):
 def assert_frame_equal(a, b, frame, check_transformed=False):
     """a, b: HopeContext objects that just ran the same input.  Bit-exact on every stage."""
     ca, cb = a.counts(frame), b.counts(frame)
-    for k in ("n_in", "n_raw", "n_vox", "n_fit", "n_segments", "n_clusters", "n_planes", "status"):
+    for k in ("n_in", "n_raw", "n_vox", "n_fit", "n_segments", "n_clusters", "n_planes", "status", "vox_passthrough"):
         assert getattr(ca, k) == getattr(cb, k), (frame, k, getattr(ca, k), getattr(cb, k))
     if ca.n_raw > 0:
         assert list(ca.grid) == list(cb.grid), (frame, list(ca.grid), list(cb.grid))

@@ -234,6 +234,73 @@ def test_depth_frames_through_two_passes(hip_lib, oracle_lib, monkeypatch):
         assert_frame_equal(o2, g2, f)
 
 
+def test_voxelgrid_pass_through_of_a_wide_cloud(hip_lib, oracle_lib):
+    """PCL's VoxelGrid refuses a grid of more than INT_MAX cells ("Leaf size is too small for the input
+    dataset") and copies its input through (voxel_grid.hpp applyFilter); A6..A12 then run on the raw
+    points.  Table-sized patches scattered over 300 m x 300 m x 20 m: 6000 x 6000 x 1000 cells."""
+    rng = np.random.default_rng(11)
+    parts = []
+    for k in range(24):
+        c = rng.uniform([-150, -150, 0], [150, 150, 20])
+        n = 500 if k % 3 else 1500   # (the dense patches exceed the 32-neighbour list: selection by rescan)
+        p = np.empty((n, 3), np.float32)
+        p[:, :2] = c[:2] + rng.uniform(-0.25, 0.25, (n, 2))
+        p[:, 2] = c[2] + rng.normal(0, 0.002, n)
+        if k % 5 == 4:   # a wall: fails the normal gate
+            p[:, 0] = c[0] + rng.normal(0, 0.002, n)
+            p[:, 2] = c[2] + rng.uniform(0, 0.5, n)
+        parts.append(p)
+    xyz = np.concatenate(parts)
+    xyz = xyz[rng.permutation(len(xyz))]
+    xyz[7] = [-0.0, 3.0, 1.0]
+    xyz[100] = [np.nan, 0, 0]
+    g, o = both(hip_lib, oracle_lib)
+    for c in (g, o):
+        assert c.segment_cloud(xyz) == 0
+    k = g.counts(0)
+    assert k.vox_passthrough == 1 and k.n_vox == k.n_raw == len(xyz) - 1 and list(k.grid) == [0, 0, 0]
+    assert k.n_fit > 5000 and k.n_planes >= 10
+    assert_frame_equal(o, g, 0)
+    assert np.array_equal(g.downsampled(0).view(np.uint32), np.delete(xyz, 100, 0).view(np.uint32))
+    # with the sensor-frame filter and the pose in front
+    g, o = both(hip_lib, oracle_lib, min_depth=-1.0e3, max_depth=1.0e3)
+    for c in (g, o):
+        c.set_pose([1.0, -2.0, 0.5], [0.0, 0.0, 0.38268343, 0.92387953])
+        assert c.segment_cloud(xyz, apply_filter_transform=True) == 0
+    assert g.counts(0).vox_passthrough == 1
+    assert_frame_equal(o, g, 0, check_transformed=True)
+
+
+def test_voxelgrid_pass_through_in_a_depth_batch(hip_lib, oracle_lib):
+    """Depth frames whose grid exceeds INT_MAX cells (th_z of 0.5 um: some 75 x 50 x 2000000) share a batch
+    with a frame small enough to be down-sampled; the batch leaves the (chunk, voxel)-group path and
+    runs again on the per-point voxel stage, where a pass-through frame's points are their own voxels."""
+    depth, t, q = synth_frames(3, first=40)
+    depth = np.ascontiguousarray(depth[:, 100:220, 200:360])
+    depth[1] = 0
+    depth[1, 50:58, 70:82] = 1500   # a fronto-parallel patch: a handful of cells
+    kw = dict(th_xy=0.02, th_z=5.0e-7)
+    g, o = both(hip_lib, oracle_lib, **kw)
+    st = []
+    for c in (g, o):
+        c.set_frame_poses(t, q)
+        st.append(c.segment_depth(depth))
+    assert st[0] == st[1] >= 0   # (worst frame status: the patch of frame 1 may hold no level normal)
+    passed = [g.counts(f).vox_passthrough for f in range(3)]
+    assert passed[0] == 1 and passed[1] == 0   # (frame 2 goes by its own extent; the oracle decides alike below)
+    assert g.counts(0).n_vox == g.counts(0).n_raw > 10000
+    for f in range(3):
+        assert_frame_equal(o, g, f, check_transformed=(f == 2))
+
+
+def test_extent_beyond_any_column_index_is_refused(hip_lib):
+    """More than 2^30 columns of th_xy: neither a VoxelGrid nor a column index; HOPE_E_RANGE with a message."""
+    xyz = np.array([[0, 0, 0], [4.0e4, 4.0e4, 1.0], [1, 1, 1]], np.float32)
+    g = HopeContext(hip_lib, th_xy=0.001, th_z=0.001)
+    with pytest.raises(Exception, match="columns"):
+        g.segment_cloud(xyz)
+
+
 def test_knn_leftovers_through_the_coarse_index(hip_lib, oracle_lib, monkeypatch):
     """k-NN queries that the LDS tile cannot settle go through a whole-frame ring expansion: over the
     fine column index when few, over the coarse index of the fit points when many.  The knob sets the
