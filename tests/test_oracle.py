@@ -155,3 +155,23 @@ def test_rt_height_window_and_merge(oracle_lib):
     c.set_height_window(3.0, 4.0)
     c.segment_depth(z["depth"])
     assert c.max_plane(0).valid == 0
+
+
+def test_voxelgrid_leaf_too_small_passes_the_input_through(oracle_lib):
+    """PCL 1.8.1 voxel_grid.hpp applyFilter: (dx*dy*dz) > INT_MAX -> warning, output = *input.  Two level
+    patches 300 m apart at the default leaf (6000 x 6000 x 400 cells): the down-sampled cloud is the
+    input, point for point, and both patches still come out as planes."""
+    rng = np.random.default_rng(5)
+    a = np.stack([rng.uniform(0, 0.4, 600), rng.uniform(0, 0.4, 600), rng.normal(0.7, 0.002, 600)], 1)
+    b = a + [300.0, 300.0, 8.0]
+    xyz = np.concatenate([a, b]).astype(np.float32)
+    c = HopeContext(oracle_lib)
+    assert c.segment_cloud(xyz) == 0
+    k = c.counts(0)
+    assert k.vox_passthrough == 1 and k.n_vox == k.n_raw == 1200 and list(k.grid) == [0, 0, 0]
+    assert np.array_equal(c.downsampled(0).view(np.uint32), xyz.view(np.uint32))
+    assert k.n_planes == 2
+    # the same patches side by side fit the grid and are down-sampled
+    near = np.concatenate([a, a + [1.0, 0.0, 0.3]]).astype(np.float32)
+    assert c.segment_cloud(near) == 0
+    assert c.counts(0).vox_passthrough == 0 and c.counts(0).n_vox < 300
