@@ -348,7 +348,6 @@ inline bool depth8_ok(const DepthSrc& s)
 {
   return (s.w % 8) == 0 && (reinterpret_cast<uintptr_t>(s.depth) % 16) == 0;
 }
-inline bool depth8_ok(const CloudSrc&) { return false; }
 
 template <class VK>
 void launch_voxel_keys(hope_ctx* c, const DepthSrc& src, size_t n_per_frame, int cell_bits, VK* k_in, uint32_t* v_in)

@@ -1022,39 +1022,13 @@ __global__ void k_frame_vox_counts(FrameInfo* fi, int n_frames, const Globals* g
   fi[f].n_vox = next - fi[f].vox_start;
 }
 
-// ---- K5: voxel centroids (CentroidPoint<PointXYZ>: sequential float sum / n) -----------
-// One thread per voxel walks its points in ascending source index (the stable sort keeps
-// them so) and re-derives each point from the source instead of re-reading 12 B/pt.
-template <class Src, class KeyT>
-__global__ void __launch_bounds__(kBlock)
-k_centroids(Src src, const FrameInfo* fi, const KeyT* unique, const uint32_t* run_start, const uint32_t* run_count,
-            const uint32_t* vals_sorted, unsigned n_vox, int cell_bits, float4* vox, int* vox_frame)
-{
-  const unsigned v = blockIdx.x * kBlock + threadIdx.x;
-  if (v >= n_vox) return;
-  const int frame = (int)(unique[v] >> cell_bits);
-  const unsigned start = run_start[v], cnt = run_count[v];
-  const unsigned n = src_count(src);
-  const size_t base = (size_t)frame * n;
-  float sx = 0.f, sy = 0.f, sz = 0.f;
-  for (unsigned j = 0; j < cnt; ++j) {
-    const unsigned i = (unsigned)(vals_sorted[start + j] - base);
-    float x, y, z;
-    load_point(src, fi, frame, i, x, y, z);
-    sx += x;
-    sy += y;
-    sz += z;
-  }
-  const float c = (float)cnt;
-  vox[v] = make_float4(sx / c, sy / c, sz / c, 0.f);
-  vox_frame[v] = frame;
-}
-
-// ---- K5 (wave-cooperative): same sums, fed through LDS -----------------------------------
+// ---- K5: voxel centroids (CentroidPoint<PointXYZ>: sequential float sum / n), per-point path ---
+// A voxel's points arrive in ascending source index (the stable sort keeps them so) and are
+// re-derived from the source instead of re-read at 12 B/pt.
 // A wave owns 64 consecutive voxels (lane = voxel).  Per round it fetches the next kR entries
 // of every voxel with coalesced loads (16 lanes per voxel), re-derives the points in parallel,
 // parks them in LDS and then every lane adds ITS voxel's kR points sequentially — the same
-// ascending-index chain as the one-thread-per-voxel kernel above, but with 64 chains per wave
+// ascending-index chain as one thread per voxel would run, but with 64 chains per wave
 // running from LDS instead of 64 dependent uncoalesced gathers.
 constexpr int kR = 16;          // entries per voxel per round
 constexpr int kRStride = 65;    // LDS row stride (dwords): conflict-free reads, <=4-way writes
@@ -1902,98 +1876,9 @@ __device__ inline void principal_axis_2x2(float a, float b, float d, float& ax, 
 }
 
 // ---- K10: A10 mean z (utilities.cpp:751-769), A12 bbox (plane_segment.cpp:408-420),
-// A11 normalAnalysis (utilities.cpp:151-282).  One thread per cluster: every sum is the
-// reference's sequential float sum over the members in ascending index.
-__global__ void __launch_bounds__(kWave)
-k_cluster_verify(const uint32_t* members, const uint32_t* cl_first, const float4* fit_pt, const float4* fit_nrm,
-                 unsigned n_cl, float th_angle, ClusterRec* rec)
-{
-  const unsigned c = blockIdx.x * kWave + threadIdx.x;
-  if (c >= n_cl) return;
-  const uint32_t* m = members + cl_first[c];
-  const int sz = rec[c].size;
-  float mid = 0.f;
-  unsigned ct = 0;
-  float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-  for (int i = 0; i < sz; ++i) {
-    const unsigned g = m[i];
-    const float4 p = fit_pt[g];
-    const float4 nn = fit_nrm[g];
-    if (isfinite(p.z)) {
-      mid += p.z;
-      ++ct;
-    }
-    mnx = fminf(mnx, p.x);
-    mny = fminf(mny, p.y);
-    mxx = fmaxf(mxx, p.x);
-    mxy = fmaxf(mxy, p.y);
-    s0 += nn.x;
-    s1 += nn.y;
-    s2 += fabsf(nn.z);
-  }
-  rec[c].z_mean = mid / (float)ct;
-  rec[c].min_x = mnx;
-  rec[c].min_y = mny;
-  rec[c].max_x = mxx;
-  rec[c].max_y = mxy;
-  int pass = 0;
-  if (sz > 2) {
-    const float fsz = (float)sz;
-    const float m0 = s0 / fsz, m1 = s1 / fsz, m2 = s2 / fsz;
-    const float proj_norm = __builtin_sqrtf(m0 * m0 + m1 * m1);
-    const float mean_norm = __builtin_sqrtf(m0 * m0 + (m1 * m1 + m2 * m2));
-    const float grad = hope_det_asinf(proj_norm / mean_norm);
-    if (!(grad > th_angle)) {
-      float cxx = 0.f, cxy = 0.f, cyy = 0.f;
-      for (int i = 0; i < sz; ++i) {
-        const float4 nn = fit_nrm[m[i]];
-        const float tx = nn.x - m0, ty = nn.y - m1;
-        cxx += tx * tx;
-        cxy += tx * ty;
-        cyy += ty * ty;
-      }
-      const float denom = (float)(sz - 1);
-      cxx /= denom;
-      cxy /= denom;
-      cyy /= denom;
-      float ax, ay;
-      principal_axis_2x2(cxx, cxy, cyy, ax, ay);
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
-      unsigned na = 0, nb = 0;
-      for (int i = 0; i < sz; ++i) {
-        const float4 nn = fit_nrm[m[i]];
-        const float nz = fabsf(nn.z);
-        const float tx = nn.x - m0, ty = nn.y - m1;
-        if (ax * tx + ay * ty > 0.f) {
-          a0 += nn.x;
-          a1 += nn.y;
-          a2 += nz;
-          ++na;
-        } else {
-          b0 += nn.x;
-          b1 += nn.y;
-          b2 += nz;
-          ++nb;
-        }
-      }
-      if (na != 0 && nb != 0) {
-        const float fa = (float)na, fb = (float)nb;
-        const float p1[3] = {a0 / fa, a1 / fa, a2 / fa};
-        const float p2[3] = {b0 / fb, b1 / fb, b2 / fb};
-        const float mu = p2[0] * p1[0] + (p2[1] * p1[1] + p2[2] * p1[2]);
-        const float n1 = __builtin_sqrtf(sqnorm3(p1));
-        const float n2 = __builtin_sqrtf(sqnorm3(p2));
-        const float rad_mu = hope_det_acosf(mu / (n1 * n2));
-        pass = (rad_mu <= th_angle) ? 1 : 0;
-      }
-    }
-  }
-  rec[c].pass = pass;
-}
-
-// ---- K10 (block per cluster) --------------------------------------------------------------
-// Same sequential sums as k_cluster_verify, organised for the hardware.  The reference's sums are
+// A11 normalAnalysis (utilities.cpp:151-282).  Every sum is the reference's sequential float sum
+// over the members in ascending index.
+// One block per cluster.  The reference's sums are
 // chains of dependent float adds in member order; a chain cannot be split, but the work around it
 // can: waves 1..3 of the block are LOADERS -- they fetch the members' points / normals (coalesced
 // index loads one tile ahead, 16-byte gathers) and park the per-point terms in LDS, double
