@@ -160,6 +160,7 @@ struct hope_ctx {
   float fast_div_key[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   int ablate = 0;             // timing experiments only (HOPE_DEBUG_ABLATE): wrong results
   int pixel_sort = 0;         // test knob: depth frames through the per-pixel sort (the cloud path's voxel stage)
+  int col_sort_z = 0;         // test knob HOPE_DEBUG_COLSORT_Z=1: z cell bits in the column sort key even for VoxelGrid output
   int seg_sort = 1;           // per-frame segmented sort of the group records (HOPE_DEBUG_SEGSORT=0: device-wide sort)
   uint32_t* d_grp_cnt = nullptr;  // depth path: groups per chunk, then its exclusive scan
   uint32_t* d_grp_off = nullptr;
@@ -582,20 +583,26 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   ALLOC(cv_out, uint32_t, n_vox);
   ALLOC(col_first, uint32_t, (size_t)total_cols + 1);
   ALLOC(spt, float4, n_vox);
+  // VoxelGrid output arrives in voxel order (z cell, then y, then x): a STABLE sort by column alone leaves
+  // every column ascending in z cell, which is all the searches need (one radix pass fewer).  A cloud
+  // adopted as it is, or passed through, comes in input order and keeps the z cell in its key.
+  const bool col_only = !c->col_sort_z && !c->input_is_downsampled && !(c->h_glob->any_overflow & 1u);
+  const int czbits = col_only ? 0 : zbits;
+  const int ckey_bits = key2_bits - zbits + czbits;
   size_t pm = prof_mark(c);
   hipLaunchKernelGGL((k_column_keys<CK>), dim3(nblk(n_vox)), dim3(kBlock), 0, s, d_vox, d_vox_frame, c->d_fi,
-                     n_vox, c->inv_xy, c->inv_z, zbits, ck_in, cv_in);
+                     n_vox, c->inv_xy, c->inv_z, czbits, ck_in, cv_in);
   prof_close(c, ST_COLKEYS, pm, (16.0 + 4.0 + sizeof(CK) + 4.0) * n_vox);
   pm = prof_mark(c);
   if (sizeof(CK) == 4) {
-    HIPCHK(sort_pairs_u32(pa, (const uint32_t*)ck_in, (uint32_t*)ck_out, cv_in, cv_out, n_vox, key2_bits, s));
+    HIPCHK(sort_pairs_u32(pa, (const uint32_t*)ck_in, (uint32_t*)ck_out, cv_in, cv_out, n_vox, ckey_bits, s));
   } else {
-    HIPCHK(sort_pairs_u64(pa, (const uint64_t*)ck_in, (uint64_t*)ck_out, cv_in, cv_out, n_vox, key2_bits, s));
+    HIPCHK(sort_pairs_u64(pa, (const uint64_t*)ck_in, (uint64_t*)ck_out, cv_in, cv_out, n_vox, ckey_bits, s));
   }
   prof_close(c, ST_COLSORT, pm, 2.0 * (sizeof(CK) + 4.0) * n_vox);
   pm = prof_mark(c);
   hipLaunchKernelGGL((k_column_table<CK>), dim3(nblk((size_t)n_vox + 1)), dim3(kBlock), 0, s, ck_out, n_vox,
-                     total_cols, zbits, col_first);
+                     total_cols, czbits, col_first);
   hipLaunchKernelGGL(k_gather_sorted, dim3(nblk(n_vox)), dim3(kBlock), 0, s, d_vox, cv_out, n_vox, spt);
   prof_close(c, ST_COLTABLE, pm, (4.0 + 16.0 + 16.0) * n_vox + 4.0 * total_cols);
 
@@ -1093,6 +1100,8 @@ HOPE_API int hope_create(const hope_config* cfg, hope_ctx** out)
   c->pixel_sort = (knob && knob[0] == '1') ? 1 : 0;
   knob = std::getenv("HOPE_DEBUG_TWO_PASS");
   c->two_pass = (knob && knob[0] == '1') ? 1 : 0;
+  knob = std::getenv("HOPE_DEBUG_COLSORT_Z");
+  c->col_sort_z = (knob && knob[0] == '1') ? 1 : 0;
   knob = std::getenv("HOPE_DEBUG_SEGSORT");
   c->seg_sort = (knob && knob[0] == '0') ? 0 : 1;
   *out = c;

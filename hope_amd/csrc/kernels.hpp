@@ -1134,7 +1134,7 @@ k_column_keys(const float4* vox, const int* vox_frame, const FrameInfo* fi, unsi
   const int cy = clampi(cell_unclamped(p.y, inv_xy, F.min_b[1]), 0, F.div_b[1] - 1);
   const int cz = clampi(cell_unclamped(p.z, inv_z, F.min_b[2]), 0, F.div_b[2] - 1);
   const unsigned col = (unsigned)F.col_off + (unsigned)(cy * F.div_b[0] + cx);
-  keys[v] = ((KeyT)col << zbits) | (KeyT)(unsigned)cz;
+  keys[v] = zbits ? (((KeyT)col << zbits) | (KeyT)(unsigned)cz) : (KeyT)col;  // (zbits 0: by column alone)
   vals[v] = v;
 }
 
