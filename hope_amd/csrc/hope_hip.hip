@@ -806,25 +806,20 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   }
 
   // ---- segments -> clusters (size filter, z_growing.cpp:149-162) ---------------------
-  uint32_t *cnt, *is_seg, *is_cl, *cl_pts, *scan_seg, *scan_cl, *scan_pts;
+  uint32_t* cnt;
+  U3 *seg_flags, *seg_scan;  // (is a segment, is a cluster, points of the cluster) per seed rank and their scans
   ALLOC(cnt, uint32_t, (size_t)n_fit + 1);
-  ALLOC(is_seg, uint32_t, (size_t)n_fit + 1);
-  ALLOC(is_cl, uint32_t, (size_t)n_fit + 1);
-  ALLOC(cl_pts, uint32_t, (size_t)n_fit + 1);
-  ALLOC(scan_seg, uint32_t, (size_t)n_fit + 1);
-  ALLOC(scan_cl, uint32_t, (size_t)n_fit + 1);
-  ALLOC(scan_pts, uint32_t, (size_t)n_fit + 1);
+  ALLOC(seg_flags, U3, (size_t)n_fit + 1);
+  ALLOC(seg_scan, U3, (size_t)n_fit + 1);
   pm = prof_mark(c);
   HIPCHK(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * ((size_t)n_fit + 1), s));
   hipLaunchKernelGGL(k_segment_sizes, dim3(gb), dim3(kBlock), 0, s, root, L, n_fit, label, cnt);
   hipLaunchKernelGGL(k_segment_flags, dim3(nblk((size_t)n_fit + 1)), dim3(kBlock), 0, s, cnt, n_fit,
-                     c->cfg.min_cluster, is_seg, is_cl, cl_pts);
-  HIPCHK(exclusive_scan_u32(pa, is_seg, scan_seg, (size_t)n_fit + 1, s));
-  HIPCHK(exclusive_scan_u32(pa, is_cl, scan_cl, (size_t)n_fit + 1, s));
-  HIPCHK(exclusive_scan_u32(pa, cl_pts, scan_pts, (size_t)n_fit + 1, s));
-  hipLaunchKernelGGL(k_frame_cluster_ranges, dim3(nblk(F)), dim3(kBlock), 0, s, c->d_fi, F, scan_seg, scan_cl);
+                     c->cfg.min_cluster, seg_flags);
+  HIPCHK(exclusive_scan_u32x3(pa, seg_flags, seg_scan, (size_t)n_fit + 1, s));
+  hipLaunchKernelGGL(k_frame_cluster_ranges, dim3(nblk(F)), dim3(kBlock), 0, s, c->d_fi, F, seg_scan);
   prof_close(c, ST_SEGMENTS, pm, (4.0 + 4.0 + 4.0 + 7 * 4.0) * n_fit);
-  HIPCHK(hipMemcpyAsync(h_cnt, scan_cl + n_fit, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(h_cnt, &seg_scan[n_fit].b, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   const unsigned n_cl = *h_cnt;
   c->n_cl_total = n_cl;
@@ -843,11 +838,11 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   c->d_members = members;
   c->d_cl_first = cl_first;
   pm = prof_mark(c);
-  hipLaunchKernelGGL(k_point_clusters, dim3(gb), dim3(kBlock), 0, s, label, is_cl, scan_cl, n_fit, n_cl, cid, mkey,
+  hipLaunchKernelGGL(k_point_clusters, dim3(gb), dim3(kBlock), 0, s, label, seg_flags, seg_scan, n_fit, n_cl, cid, mkey,
                      mval);
   if (n_cl > 0) {
     HIPCHK(sort_pairs_u32(pa, mkey, mkey_s, mval, members, n_fit, bits_for(n_cl), s));
-    hipLaunchKernelGGL(k_cluster_heads, dim3(gb), dim3(kBlock), 0, s, cnt, is_cl, scan_cl, scan_pts, seed_node,
+    hipLaunchKernelGGL(k_cluster_heads, dim3(gb), dim3(kBlock), 0, s, cnt, seg_flags, seg_scan, seed_node,
                        fit_frame, c->d_fi, n_fit, cl_first, rec);
     prof_close(c, ST_SEGMENTS, pm, (4.0 + 4.0 + 2 * 8.0 + 2 * 8.0) * n_fit);
     pm = prof_mark(c);

@@ -12,6 +12,7 @@
 
 #include "../../include/hope_detmath.h"
 #include "../../include/hope_gpu.h"
+#include "prims.hpp"
 
 namespace hope {
 
@@ -1792,40 +1793,37 @@ k_segment_sizes(const int* root, const int* L, unsigned n_fit, int* label, uint3
 }
 
 __global__ void __launch_bounds__(kBlock)
-k_segment_flags(const uint32_t* cnt, unsigned n_fit, int min_cluster, uint32_t* is_seg, uint32_t* is_cl,
-                uint32_t* cl_pts)
+k_segment_flags(const uint32_t* cnt, unsigned n_fit, int min_cluster, U3* flags)
 {
+  // per seed rank: (.a is a segment, .b is a cluster, .c points of the cluster); one scan for the three
   const unsigned r = blockIdx.x * kBlock + threadIdx.x;
   if (r > n_fit) return;
   const uint32_t c = r < n_fit ? cnt[r] : 0u;
-  is_seg[r] = c > 0u;
   const bool cl = c >= (uint32_t)min_cluster;  // and <= INT_MAX, z_growing.cpp:153-154
-  is_cl[r] = cl;
-  cl_pts[r] = cl ? c : 0u;
+  flags[r] = U3{c > 0u ? 1u : 0u, cl ? 1u : 0u, cl ? c : 0u};
 }
 
-__global__ void k_frame_cluster_ranges(FrameInfo* fi, int n_frames, const uint32_t* scan_seg,
-                                       const uint32_t* scan_cl)
+__global__ void k_frame_cluster_ranges(FrameInfo* fi, int n_frames, const U3* scan)
 {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= n_frames) return;
-  const int a = fi[f].fit_start, b = fi[f].fit_start + fi[f].n_fit;
-  fi[f].seg_start = (int)scan_seg[a];
-  fi[f].n_segments = (int)(scan_seg[b] - scan_seg[a]);
-  fi[f].cl_start = (int)scan_cl[a];
-  fi[f].n_clusters = (int)(scan_cl[b] - scan_cl[a]);
+  const U3 a = scan[fi[f].fit_start], b = scan[fi[f].fit_start + fi[f].n_fit];
+  fi[f].seg_start = (int)a.a;
+  fi[f].n_segments = (int)(b.a - a.a);
+  fi[f].cl_start = (int)a.b;
+  fi[f].n_clusters = (int)(b.b - a.b);
 }
 
 // cluster id of every fit point (-1: its segment was dropped by the size filter) and the
 // sort key that groups members by cluster
 __global__ void __launch_bounds__(kBlock)
-k_point_clusters(const int* label, const uint32_t* is_cl, const uint32_t* scan_cl, unsigned n_fit,
-                 unsigned n_cl_total, int* cid, uint32_t* mkey, uint32_t* mval)
+k_point_clusters(const int* label, const U3* flags, const U3* scan, unsigned n_fit, unsigned n_cl_total, int* cid,
+                 uint32_t* mkey, uint32_t* mval)
 {
   const unsigned g = blockIdx.x * kBlock + threadIdx.x;
   if (g >= n_fit) return;
   const int a = label[g];
-  const int c = is_cl[a] ? (int)scan_cl[a] : -1;
+  const int c = flags[a].b ? (int)scan[a].b : -1;
   cid[g] = c;
   mkey[g] = c >= 0 ? (uint32_t)c : n_cl_total;
   mval[g] = g;
@@ -1840,14 +1838,13 @@ struct ClusterRec {  // == hope_cluster
 };
 
 __global__ void __launch_bounds__(kBlock)
-k_cluster_heads(const uint32_t* cnt, const uint32_t* is_cl, const uint32_t* scan_cl, const uint32_t* scan_pts,
-                const int* seed_node, const int* fit_frame, const FrameInfo* fi, unsigned n_fit,
-                uint32_t* cl_first, ClusterRec* rec)
+k_cluster_heads(const uint32_t* cnt, const U3* flags, const U3* scan, const int* seed_node, const int* fit_frame,
+                const FrameInfo* fi, unsigned n_fit, uint32_t* cl_first, ClusterRec* rec)
 {
   const unsigned r = blockIdx.x * kBlock + threadIdx.x;
-  if (r >= n_fit || !is_cl[r]) return;
-  const unsigned c = scan_cl[r];
-  cl_first[c] = scan_pts[r];
+  if (r >= n_fit || !flags[r].b) return;
+  const unsigned c = scan[r].b;
+  cl_first[c] = scan[r].c;
   rec[c].size = (int)cnt[r];
   rec[c].seed_rank = (int)r - fi[fit_frame[seed_node[r]]].fit_start;
 }

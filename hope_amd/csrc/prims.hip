@@ -85,4 +85,19 @@ hipError_t exclusive_scan_u32(const PrimAlloc& a, const uint32_t* in, uint32_t* 
   return rocprim::exclusive_scan(tmp, bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), s);
 }
 
+struct PlusU3 {
+  __host__ __device__ U3 operator()(const U3& x, const U3& y) const { return U3{x.a + y.a, x.b + y.b, x.c + y.c}; }
+};
+
+hipError_t exclusive_scan_u32x3(const PrimAlloc& a, const U3* in, U3* out, size_t n, hipStream_t s)
+{
+  if (n == 0) return hipSuccess;
+  size_t bytes = 0;
+  hipError_t e = rocprim::exclusive_scan(nullptr, bytes, in, out, U3{0u, 0u, 0u}, n, PlusU3(), s);
+  if (e != hipSuccess) return e;
+  void* tmp = a(bytes ? bytes : 16);
+  if (!tmp) return hipErrorOutOfMemory;
+  return rocprim::exclusive_scan(tmp, bytes, in, out, U3{0u, 0u, 0u}, n, PlusU3(), s);
+}
+
 }  // namespace hope

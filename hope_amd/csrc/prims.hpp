@@ -33,5 +33,10 @@ hipError_t rle_u64(const PrimAlloc& a, const uint64_t* keys, size_t n, uint64_t*
                    uint32_t* n_runs, hipStream_t s);
 // out[i] = sum_{j<i} in[j]
 hipError_t exclusive_scan_u32(const PrimAlloc& a, const uint32_t* in, uint32_t* out, size_t n, hipStream_t s);
+// three independent scans in one pass (component-wise sums)
+struct U3 {
+  uint32_t a, b, c;
+};
+hipError_t exclusive_scan_u32x3(const PrimAlloc& a, const U3* in, U3* out, size_t n, hipStream_t s);
 
 }  // namespace hope
