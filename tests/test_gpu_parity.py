@@ -301,6 +301,23 @@ def test_extent_beyond_any_column_index_is_refused(hip_lib):
         g.segment_cloud(xyz)
 
 
+def test_column_sort_with_and_without_the_z_cell(hip_lib, oracle_lib, monkeypatch):
+    """VoxelGrid output is sorted by column alone (the stable sort keeps the voxel order, ascending in z
+    cell); the knob puts the z cell back into the key, as adopted and passed-through clouds have it.
+    Either order of a column's entries must give the same bits."""
+    depth, t, q = synth_frames(3, first=61)
+    monkeypatch.setenv("HOPE_DEBUG_COLSORT_Z", "1")
+    g = HopeContext(hip_lib)
+    monkeypatch.delenv("HOPE_DEBUG_COLSORT_Z")
+    g2, o = HopeContext(hip_lib), HopeContext(oracle_lib)
+    for c in (g, g2, o):
+        c.set_frame_poses(t, q)
+        assert c.segment_depth(depth) == 0
+    for f in range(3):
+        assert_frame_equal(o, g, f)
+        assert_frame_equal(o, g2, f)
+
+
 def test_knn_leftovers_through_the_coarse_index(hip_lib, oracle_lib, monkeypatch):
     """k-NN queries that the LDS tile cannot settle go through a whole-frame ring expansion: over the
     fine column index when few, over the coarse index of the fit points when many.  The knob sets the
