@@ -70,7 +70,7 @@ ABI_SYMBOLS = [
     "config_default", "create", "destroy", "last_error", "set_pose", "set_frame_poses",
     "set_height_window", "segment_depth_u16", "segment_cloud_xyz", "num_frames",
     "frame_counts", "get_transformed", "get_downsampled", "get_normals", "get_fit_indices",
-    "get_knn", "get_labels", "get_clusters", "get_cluster_indices", "get_max_plane",
+    "get_knn", "get_labels", "get_clusters", "get_cluster_indices", "get_max_plane", "get_max_plane_members",
     "last_timing", "grid_from_bbox", "shard_bbox", "shard_z_histogram", "shard_route",
     "downsample_cloud_bbox", "segment_downsampled", "segment_downsampled_staged",
     "get_normals_rows", "get_knn_rows", "get_downsampled_to",
@@ -115,6 +115,7 @@ class HopeLib:
             "get_clusters": (C.c_int, [vp, i32, vp, i32]),
             "get_cluster_indices": (C.c_int, [vp, i32, i32, vp, i32]),
             "get_max_plane": (C.c_int, [vp, i32, C.POINTER(HopeMaxPlane)]),
+            "get_max_plane_members": (C.c_int, [vp, i32, vp, i32]),
             "last_timing": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
             "grid_from_bbox": (C.c_int, [vp, vp, vp, vp]),
             "shard_bbox": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, i32, i32, vp, C.POINTER(C.c_int64)]),
@@ -392,6 +393,15 @@ class HopeContext:
         m = HopeMaxPlane()
         self._check(self.lib.fn["get_max_plane"](self._h, frame, C.byref(m)), "get_max_plane")
         return m
+
+    def max_plane_members(self, frame=0):
+        """Every cluster of the RT winner (max_plane_cloud_), in point order; no limit on their number."""
+        n = self._check(self.lib.fn["get_max_plane_members"](self._h, frame, None, 0), "get_max_plane_members")
+        out = np.zeros(max(n, 1), np.int32)
+        got = self._check(self.lib.fn["get_max_plane_members"](self._h, frame, out.ctypes.data, n),
+                          "get_max_plane_members")
+        assert got == n
+        return [int(v) for v in out[:n]]
 
     def clusters_upon_plane(self, contour_xyz, frame=0, tolerance=0.01, min_size=10, max_size=240000):
         """Utilities::getClustersUponPlane on the last call's src_mono_cloud_: returns

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels.hpp"
@@ -82,6 +83,13 @@ struct Arena {
     for (Block& b : blocks) (void)hipFree(b.p);
     blocks.clear();
   }
+};
+
+struct ArenaScope {  // everything allocated while it lives is given back
+  Arena& a;
+  std::vector<size_t> m;
+  explicit ArenaScope(Arena& ar) : a(ar), m(ar.mark()) {}
+  ~ArenaScope() { a.rollback(m); }
 };
 
 void* arena_alloc_cb(void* user, size_t bytes) { return static_cast<Arena*>(user)->alloc(bytes); }
@@ -158,7 +166,7 @@ struct hope_ctx {
   int force_ieee_div = 0;     // test knob HOPE_DEBUG_IEEE_DIV
   int fast_div = 0;           // div_const<true> verified for fast_div_key (the current camera model)
   float fast_div_key[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  int ablate = 0;             // timing experiments only (HOPE_DEBUG_ABLATE): wrong results
+  int ablate = 0;             // timing experiments only (-DHOPE_ABLATE builds read HOPE_DEBUG_ABLATE): wrong results
   int pixel_sort = 0;         // test knob: depth frames through the per-pixel sort (the cloud path's voxel stage)
   int col_sort_z = 0;         // test knob HOPE_DEBUG_COLSORT_Z=1: z cell bits in the column sort key even for VoxelGrid output
   int seg_sort = 1;           // per-frame segmented sort of the group records (HOPE_DEBUG_SEGSORT=0: device-wide sort)
@@ -179,6 +187,7 @@ struct hope_ctx {
   std::vector<FrameInfo> h_fi;
   std::vector<ClusterRec> h_rec;
   std::vector<hope_max_plane> h_max;
+  std::vector<std::vector<int32_t>> h_max_members;  // RT winner: every member cluster, in max_plane_cloud_ order
   std::vector<int> h_nplanes;
   FrameInfo* d_fi = nullptr;
   float4* d_vox = nullptr;
@@ -196,6 +205,17 @@ struct hope_ctx {
   int* d_upon_src = nullptr;
   std::vector<size_t> upon_mark;   // arena fill levels before the last F1 call (rolled back by the next one)
   bool upon_mark_valid = false;
+
+  // ---- sub-batches of a large depth batch ------------------------------------------------
+  // Frames are independent, so a batch of many frames is cut into n_sub contiguous ranges, each run
+  // by a child context of its own (own stream, own workspace) on a host thread of its own: while one
+  // range waits for a count to come back or runs a kernel that cannot fill the chip (a chain of
+  // dependent adds, one workgroup per frame), the kernels of the other ranges use the idle CUs.
+  int n_sub = 4;                  // HOPE_SUB_BATCHES (1: never split)
+  int sub_min_frames = 64;        // HOPE_DEBUG_SUB_MIN: frames per range below which a batch is not cut further
+  std::vector<hope_ctx*> kids;
+  std::vector<int> kid_first;     // last call: kid k holds frames [kid_first[k], kid_first[k+1]); empty: not split
+  hope_ctx* upon_kid = nullptr;   // kid that ran the last hope_clusters_upon_plane
 };
 
 namespace {
@@ -303,14 +323,18 @@ void prof_collect(hope_ctx* c)  // call after the stream has been synchronised
   p.used = 0;
 }
 
-// PlaneSegmentRT::getPlane's winner logic over the cluster records (plane_segment.cpp:930-962)
+// PlaneSegmentRT::getPlane's winner logic over the cluster records (plane_segment.cpp:930-962).
+// max_plane_cloud_ is kept as the list of the clusters whose points it concatenates, without any
+// limit (combineCloud appends the old max plane AFTER the new cluster, utilities.cpp:1717-1727).
 void rt_post(hope_ctx* c)
 {
   c->h_max.assign(c->n_frames, hope_max_plane{});
+  c->h_max_members.assign(c->n_frames, std::vector<int32_t>());
   c->h_nplanes.assign(c->n_frames, 0);
   for (int f = 0; f < c->n_frames; ++f) {
     const FrameInfo& F = c->h_fi[f];
     hope_max_plane& mp = c->h_max[f];
+    std::vector<int32_t>& mem = c->h_max_members[f];
     mp.z = -1000.0f;
     int n_planes = 0;
     for (int ci = 0; ci < F.n_clusters; ++ci) {
@@ -323,24 +347,18 @@ void rt_post(hope_ctx* c)
       if (!(z_in > c->cfg.min_height && z_in < c->cfg.max_height)) continue;
       if (!r.pass) continue;
       ++n_planes;
-      int members[17];
-      int nm = 0;
-      members[nm++] = ci;
       int count = r.size;
-      if (c->cfg.aggressive_merge && mp.valid) {
-        if (std::fabs(mp.z - z_in) <= c->cfg.th_z) {
-          for (int m = 0; m < mp.n_members && nm < 16; ++m) members[nm++] = mp.members[m];
-          count += mp.n_points;
-        }
-      }
+      const bool merge = c->cfg.aggressive_merge && mp.valid && std::fabs(mp.z - z_in) <= c->cfg.th_z;
+      if (merge) count += mp.n_points;
       if (count > mp.n_points) {
+        if (merge) mem.insert(mem.begin(), ci); else mem.assign(1, ci);
         mp.valid = 1;
         mp.n_points = count;
         mp.z = z_in;
-        mp.n_members = std::min(nm, 16);
-        for (int m = 0; m < mp.n_members; ++m) mp.members[m] = members[m];
       }
     }
+    mp.n_members = (int32_t)mem.size();
+    for (size_t m = 0; m < mem.size() && m < 16; ++m) mp.members[m] = mem[m];
     c->h_nplanes[f] = n_planes;
   }
 }
@@ -789,6 +807,7 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   const unsigned ge = std::min(gb, 2048u);
   // Sweeps until a whole (shortcut, sweep) pair changes nothing.  Only the last pair of a batch is
   // watched, so the usual case (a fixed point within three pairs) costs one read-back, not one per pair.
+  bool converged = false;
   for (int iter = 0; iter < 100000; ++iter) {
     pm = prof_mark(c);
     const int pairs = iter == 0 ? 4 : 2;
@@ -802,7 +821,14 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
     prof_close(c, ST_LABELS, pm, 2.0 * 4.0 * n_fit);
     int st = sync_globals(c);
     if (st != HOPE_OK) return st;
-    if (!c->h_glob->changed) break;
+    if (!c->h_glob->changed) {
+      converged = true;
+      break;
+    }
+  }
+  if (!converged) {
+    c->err = "label sweeps did not reach a fixed point";
+    return HOPE_E_RANGE;
   }
 
   // ---- segments -> clusters (size filter, z_growing.cpp:149-162) ---------------------
@@ -911,6 +937,7 @@ int run_pipeline(hope_ctx* c, const Src& src, size_t n_per_frame)
   c->h_rec.clear();
   c->h_nplanes.assign(F, 0);
   c->h_max.assign(F, hope_max_plane{});
+  c->h_max_members.assign(F, std::vector<int32_t>());
   c->d_vox = nullptr;
   c->d_normals = nullptr;
   c->d_fit_idx = nullptr;
@@ -1085,8 +1112,10 @@ HOPE_API int hope_create(const hope_config* cfg, hope_ctx** out)
   }
   const char* knob = std::getenv("HOPE_DEBUG_SMALL_NB_CAP");
   c->normals_cap_small = (knob && knob[0] == '1') ? 1 : 0;
+#ifdef HOPE_ABLATE  // timing experiments (tools/ablate.sh builds its own library): never in the shipped build
   knob = std::getenv("HOPE_DEBUG_ABLATE");
   c->ablate = knob ? std::atoi(knob) : 0;
+#endif
   knob = std::getenv("HOPE_DEBUG_KNN_FINE_LIMIT");
   if (knob) c->knn_fine_limit = (unsigned)std::atoll(knob);
   knob = std::getenv("HOPE_DEBUG_IEEE_DIV");
@@ -1097,6 +1126,10 @@ HOPE_API int hope_create(const hope_config* cfg, hope_ctx** out)
   c->two_pass = (knob && knob[0] == '1') ? 1 : 0;
   knob = std::getenv("HOPE_DEBUG_COLSORT_Z");
   c->col_sort_z = (knob && knob[0] == '1') ? 1 : 0;
+  knob = std::getenv("HOPE_SUB_BATCHES");
+  if (knob && std::atoi(knob) >= 1) c->n_sub = std::min(std::atoi(knob), 16);
+  knob = std::getenv("HOPE_DEBUG_SUB_MIN");
+  if (knob && std::atoi(knob) >= 1) c->sub_min_frames = std::atoi(knob);
   knob = std::getenv("HOPE_DEBUG_SEGSORT");
   c->seg_sort = (knob && knob[0] == '0') ? 0 : 1;
   *out = c;
@@ -1106,6 +1139,8 @@ HOPE_API int hope_create(const hope_config* cfg, hope_ctx** out)
 HOPE_API void hope_destroy(hope_ctx* c)
 {
   if (!c) return;
+  for (hope_ctx* k : c->kids) hope_destroy(k);
+  c->kids.clear();
   (void)hipSetDevice(c->cfg.device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->arena.release();
@@ -1148,6 +1183,82 @@ HOPE_API int hope_set_height_window(hope_ctx* c, float mn, float mx)
   return HOPE_OK;
 }
 
+HOPE_API int hope_segment_depth_u16(hope_ctx* c, const uint16_t* depth, int w, int h, int n_frames, int on_device);
+
+// A depth batch in n_sub ranges of frames, one child context and one host thread per range.
+static int segment_depth_split(hope_ctx* c, const uint16_t* depth, int w, int h, int n_frames, int on_device, int n_sub)
+{
+  const auto t0 = std::chrono::steady_clock::now();
+  while ((int)c->kids.size() < n_sub) {
+    hope_ctx* k = nullptr;
+    const int st = hope_create(&c->cfg, &k);
+    if (st != HOPE_OK) {
+      c->err = "could not create a sub-batch context";
+      return st;
+    }
+    k->n_sub = 1;
+    c->kids.push_back(k);
+  }
+  std::vector<int> first(n_sub + 1);
+  for (int k = 0; k <= n_sub; ++k) first[k] = (int)((long long)n_frames * k / n_sub);
+  const size_t ppf = (size_t)w * h;
+  std::vector<int> status(n_sub, HOPE_OK);
+  std::vector<std::thread> th;
+  for (int k = 0; k < n_sub; ++k) {
+    hope_ctx* kid = c->kids[k];
+    kid->cfg = c->cfg;  // (the height window may have moved since the kid was made)
+    kid->pose = c->pose;
+    kid->frame_poses.clear();
+    if (!c->frame_poses.empty())
+      kid->frame_poses.assign(c->frame_poses.begin() + first[k], c->frame_poses.begin() + first[k + 1]);
+    kid->prof.on = c->prof.on;
+    th.emplace_back([=, &status]() {
+      status[k] = hope_segment_depth_u16(kid, depth + (size_t)first[k] * ppf, w, h, first[k + 1] - first[k], on_device);
+    });
+  }
+  for (std::thread& t : th) t.join();
+  int worst = HOPE_OK;
+  for (int k = 0; k < n_sub; ++k) {
+    if (status[k] < 0) {
+      c->err = c->kids[k]->err;
+      return status[k];
+    }
+    worst = std::max(worst, status[k]);
+  }
+  c->kid_first = first;
+  c->n_frames = n_frames;
+  c->src_kind = 1;
+  c->h_fi.clear();
+  c->ref_ms = 0;
+  for (int k = 0; k < n_sub; ++k) c->ref_ms += c->kids[k]->ref_ms;
+  c->whole_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return worst;
+}
+
+// frame of a split call -> (kid, frame within the kid)
+static bool route_frame(hope_ctx* c, int frame, hope_ctx*& kid, int& local)
+{
+  if (frame < 0 || frame >= c->kid_first.back()) return false;
+  const int k = (int)(std::upper_bound(c->kid_first.begin(), c->kid_first.end(), frame) - c->kid_first.begin()) - 1;
+  kid = c->kids[k];
+  local = frame - c->kid_first[k];
+  return true;
+}
+
+// first statement of every per-frame accessor: after a split call the frame lives in a kid
+#define ROUTE(c, frame, CALL)                                \
+  if ((c) && !(c)->kid_first.empty()) {                      \
+    hope_ctx* kid__ = nullptr;                               \
+    int local__ = 0;                                         \
+    if (!route_frame((c), (frame), kid__, local__)) {        \
+      (c)->err = "frame index out of range";                 \
+      return HOPE_E_RANGE;                                   \
+    }                                                        \
+    const int st__ = CALL;                                   \
+    if (st__ < 0) (c)->err = kid__->err;                     \
+    return st__;                                             \
+  }
+
 HOPE_API int hope_segment_depth_u16(hope_ctx* c, const uint16_t* depth, int w, int h, int n_frames, int on_device)
 {
   if (!c) return HOPE_E_INVALID;
@@ -1160,8 +1271,18 @@ HOPE_API int hope_segment_depth_u16(hope_ctx* c, const uint16_t* depth, int w, i
     return HOPE_E_INVALID;
   }
   HIPCHK(hipSetDevice(c->cfg.device));
+  {
+    const int n_sub = std::min(c->n_sub, n_frames / std::max(c->sub_min_frames, 1));
+    if (n_sub > 1) {
+      c->kid_first.clear();
+      c->upon_kid = nullptr;
+      return segment_depth_split(c, depth, w, h, n_frames, on_device, n_sub);
+    }
+  }
   c->arena.reset();
   c->upon_mark_valid = false;
+  c->kid_first.clear();
+  c->upon_kid = nullptr;
   c->upon.clear();
   c->n_frames = n_frames;
   c->src_kind = 1;
@@ -1213,6 +1334,8 @@ HOPE_API int hope_segment_cloud_xyz(hope_ctx* c, const void* xyz, size_t n, size
   HIPCHK(hipSetDevice(c->cfg.device));
   c->arena.reset();
   c->upon_mark_valid = false;
+  c->kid_first.clear();
+  c->upon_kid = nullptr;
   c->upon.clear();
   c->n_frames = 1;
   c->src_kind = 2;
@@ -1312,8 +1435,11 @@ HOPE_API int hope_shard_bbox(hope_ctx* c, const void* xyz, size_t n, size_t stri
                              float bbox[6], int64_t* n_raw)
 {
   if (!c || !bbox || !n_raw) return HOPE_E_INVALID;
+  c->src_kind = 0;  // (no segment result: the frame accessors that re-read the input refuse)
   c->arena.reset();
   c->upon_mark_valid = false;
+  c->kid_first.clear();
+  c->upon_kid = nullptr;
   c->upon.clear();
   CloudSrc src;
   int st = make_cloud_src(c, xyz, n, stride, apply, on_device, src);
@@ -1342,8 +1468,11 @@ HOPE_API int hope_shard_z_histogram(hope_ctx* c, const void* xyz, size_t n, size
                                     const float bbox[6], int64_t* hist, int n_bins)
 {
   if (!c || !bbox || !hist || n_bins <= 0) return HOPE_E_INVALID;
+  c->src_kind = 0;  // (no segment result: the frame accessors that re-read the input refuse)
   c->arena.reset();
   c->upon_mark_valid = false;
+  c->kid_first.clear();
+  c->upon_kid = nullptr;
   c->upon.clear();
   CloudSrc src;
   int st = make_cloud_src(c, xyz, n, stride, apply, on_device, src);
@@ -1368,8 +1497,11 @@ HOPE_API int hope_shard_route(hope_ctx* c, const void* xyz, size_t n, size_t str
                               int out_on_device, int64_t* counts)
 {
   if (!c || !bbox || !layer_owner || n_bins <= 0 || n_ranks <= 0 || !counts) return HOPE_E_INVALID;
+  c->src_kind = 0;  // (no segment result: the frame accessors that re-read the input refuse)
   c->arena.reset();
   c->upon_mark_valid = false;
+  c->kid_first.clear();
+  c->upon_kid = nullptr;
   c->upon.clear();
   CloudSrc src;
   int st = make_cloud_src(c, xyz, n, stride, apply, on_device, src);
@@ -1418,6 +1550,8 @@ static int run_cloud_staged(hope_ctx* c, const void* xyz, size_t n, size_t strid
 {
   c->arena.reset();
   c->upon_mark_valid = false;
+  c->kid_first.clear();
+  c->upon_kid = nullptr;
   c->upon.clear();
   c->n_frames = 1;
   c->src_kind = 2;
@@ -1489,10 +1623,15 @@ HOPE_API int hope_segment_downsampled_staged(hope_ctx* c, const void* vox, size_
   const FrameInfo& F = (c)->h_fi[(frame)];                    \
   (void)F;
 
-HOPE_API int hope_num_frames(const hope_ctx* c) { return c ? (int)c->h_fi.size() : HOPE_E_INVALID; }
+HOPE_API int hope_num_frames(const hope_ctx* c)
+{
+  if (!c) return HOPE_E_INVALID;
+  return c->kid_first.empty() ? (int)c->h_fi.size() : c->kid_first.back();
+}
 
 HOPE_API int hope_frame_counts(hope_ctx* c, int frame, hope_counts* out)
 {
+  ROUTE(c, frame, hope_frame_counts(kid__, local__, out));
   GET_FRAME(c, frame);
   if (!out) return HOPE_E_INVALID;
   std::memset(out, 0, sizeof(*out));
@@ -1524,11 +1663,17 @@ static int copy_out(hope_ctx* c, void* dst, const void* src, size_t bytes)
 
 HOPE_API int hope_get_transformed(hope_ctx* c, int frame, float* xyz, int32_t* src_index)
 {
+  ROUTE(c, frame, hope_get_transformed(kid__, local__, xyz, src_index));
   GET_FRAME(c, frame);
   if (!xyz || !src_index) return HOPE_E_INVALID;
   HIPCHK(hipSetDevice(c->cfg.device));
   const size_t n = c->src_kind == 1 ? c->dsrc.ppf : c->csrc.n;
   if (n == 0 || F.n_raw == 0) return HOPE_OK;
+  if (c->src_kind == 0) {
+    c->err = "hope_get_transformed: the last call on this ctx kept no input (staged shard call)";
+    return HOPE_E_INVALID;
+  }
+  const ArenaScope scope(c->arena);  // (scratch of this export only: given back on return)
   hipStream_t s = c->stream;
   PrimAlloc pa{arena_alloc_cb, &c->arena};
   uint32_t *flags, *scan;
@@ -1661,6 +1806,18 @@ int upon_plane(hope_ctx* c, const Src& src, size_t n, int frame, const float2* d
 HOPE_API int hope_clusters_upon_plane(hope_ctx* c, int frame, const float* contour_xyz, int n_contour, float tolerance, int min_size,
                                       int max_size, int32_t* n_clusters, int64_t* n_upon)
 {
+  if (c && !c->kid_first.empty()) {
+    hope_ctx* kid = nullptr;
+    int local = 0;
+    if (!route_frame(c, frame, kid, local)) {
+      c->err = "frame index out of range";
+      return HOPE_E_RANGE;
+    }
+    c->upon_kid = kid;
+    const int st = hope_clusters_upon_plane(kid, local, contour_xyz, n_contour, tolerance, min_size, max_size, n_clusters, n_upon);
+    if (st < 0) c->err = kid->err;
+    return st;
+  }
   GET_FRAME(c, frame);
   if (!contour_xyz || n_contour < 0 || !n_clusters || !(tolerance > 0.f)) return HOPE_E_INVALID;
   HIPCHK(hipSetDevice(c->cfg.device));
@@ -1671,6 +1828,10 @@ HOPE_API int hope_clusters_upon_plane(hope_ctx* c, int frame, const float* conto
   if (n_upon) *n_upon = 0;
   const size_t n = c->src_kind == 1 ? c->dsrc.ppf : c->csrc.n;
   if (n == 0 || F.n_raw == 0) return HOPE_OK;
+  if (c->src_kind == 0) {
+    c->err = "hope_clusters_upon_plane: the last call on this ctx kept no input (staged shard call)";
+    return HOPE_E_INVALID;
+  }
   // getCloudZInfo (utilities.cpp:751-769) and getStraightRect2D (utilities.cpp:1538-1560) of the contour: host scalars
   std::vector<float2> h_contour(std::max(n_contour, 1));
   float z_max = -1000.0f, mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
@@ -1701,6 +1862,7 @@ HOPE_API int hope_clusters_upon_plane(hope_ctx* c, int frame, const float* conto
 HOPE_API int hope_get_upon_cluster_sizes(hope_ctx* c, int32_t* sizes, int cap)
 {
   if (!c || !sizes) return HOPE_E_INVALID;
+  if (c->upon_kid) return hope_get_upon_cluster_sizes(c->upon_kid, sizes, cap);
   int n = 0;
   for (; n < (int)c->upon.size() && n < cap; ++n) sizes[n] = (int32_t)c->upon[n].count;
   return n;
@@ -1709,6 +1871,11 @@ HOPE_API int hope_get_upon_cluster_sizes(hope_ctx* c, int32_t* sizes, int cap)
 HOPE_API int hope_get_upon_cluster(hope_ctx* c, int cluster, float* xyz, int32_t* src_index, int cap)
 {
   if (!c || !xyz) return HOPE_E_INVALID;
+  if (c->upon_kid) {
+    const int st = hope_get_upon_cluster(c->upon_kid, cluster, xyz, src_index, cap);
+    if (st < 0) c->err = c->upon_kid->err;
+    return st;
+  }
   if (cluster < 0 || cluster >= (int)c->upon.size()) { c->err = "cluster index out of range"; return HOPE_E_RANGE; }
   const hope_ctx::UponRange r = c->upon[cluster];
   if (cap < (int)r.count) { c->err = "buffer too small"; return HOPE_E_RANGE; }
@@ -1720,6 +1887,7 @@ HOPE_API int hope_get_upon_cluster(hope_ctx* c, int cluster, float* xyz, int32_t
 
 HOPE_API int hope_get_downsampled(hope_ctx* c, int frame, float* xyz)
 {
+  ROUTE(c, frame, hope_get_downsampled(kid__, local__, xyz));
   GET_FRAME(c, frame);
   if (F.n_vox == 0) return HOPE_OK;
   if (!xyz) return HOPE_E_INVALID;
@@ -1736,6 +1904,7 @@ HOPE_API int hope_get_downsampled(hope_ctx* c, int frame, float* xyz)
 
 HOPE_API int hope_get_normals(hope_ctx* c, int frame, float* nxyzc)
 {
+  ROUTE(c, frame, hope_get_normals(kid__, local__, nxyzc));
   GET_FRAME(c, frame);
   if (F.n_vox == 0) return HOPE_OK;
   return copy_out(c, nxyzc, c->d_normals + F.vox_start, sizeof(float4) * (size_t)F.n_vox);
@@ -1743,6 +1912,7 @@ HOPE_API int hope_get_normals(hope_ctx* c, int frame, float* nxyzc)
 
 HOPE_API int hope_get_downsampled_to(hope_ctx* c, int frame, float* xyz, int out_on_device)
 {
+  ROUTE(c, frame, hope_get_downsampled_to(kid__, local__, xyz, out_on_device));
   if (!out_on_device) return hope_get_downsampled(c, frame, xyz);
   GET_FRAME(c, frame);
   if (F.n_vox == 0) return HOPE_OK;
@@ -1756,6 +1926,7 @@ HOPE_API int hope_get_downsampled_to(hope_ctx* c, int frame, float* xyz, int out
 
 HOPE_API int hope_get_normals_rows(hope_ctx* c, int frame, int64_t first, int64_t count, float* out, int out_on_device)
 {
+  ROUTE(c, frame, hope_get_normals_rows(kid__, local__, first, count, out, out_on_device));
   GET_FRAME(c, frame);
   if (first < 0 || count < 0 || first + count > F.n_vox) return HOPE_E_RANGE;
   if (count == 0) return HOPE_OK;
@@ -1769,6 +1940,7 @@ HOPE_API int hope_get_normals_rows(hope_ctx* c, int frame, int64_t first, int64_
 
 HOPE_API int hope_get_knn_rows(hope_ctx* c, int frame, int64_t first, int64_t count, int32_t* out, int out_on_device)
 {
+  ROUTE(c, frame, hope_get_knn_rows(kid__, local__, first, count, out, out_on_device));
   GET_FRAME(c, frame);
   if (first < 0 || count < 0 || first + count > F.n_fit) return HOPE_E_RANGE;
   if (count == 0) return HOPE_OK;
@@ -1790,6 +1962,7 @@ HOPE_API int hope_get_knn_rows(hope_ctx* c, int frame, int64_t first, int64_t co
 
 HOPE_API int hope_get_fit_indices(hope_ctx* c, int frame, int32_t* idx)
 {
+  ROUTE(c, frame, hope_get_fit_indices(kid__, local__, idx));
   GET_FRAME(c, frame);
   if (F.n_fit == 0) return HOPE_OK;
   int st = copy_out(c, idx, c->d_fit_idx + F.fit_start, sizeof(int32_t) * (size_t)F.n_fit);
@@ -1800,6 +1973,7 @@ HOPE_API int hope_get_fit_indices(hope_ctx* c, int frame, int32_t* idx)
 
 HOPE_API int hope_get_knn(hope_ctx* c, int frame, int32_t* nbr)
 {
+  ROUTE(c, frame, hope_get_knn(kid__, local__, nbr));
   GET_FRAME(c, frame);
   if (F.n_fit == 0) return HOPE_OK;
   const size_t cnt = (size_t)F.n_fit * c->cfg.knn;
@@ -1812,6 +1986,7 @@ HOPE_API int hope_get_knn(hope_ctx* c, int frame, int32_t* nbr)
 
 HOPE_API int hope_get_labels(hope_ctx* c, int frame, int32_t* labels)
 {
+  ROUTE(c, frame, hope_get_labels(kid__, local__, labels));
   GET_FRAME(c, frame);
   if (F.n_fit == 0) return HOPE_OK;
   int st = copy_out(c, labels, c->d_cid + F.fit_start, sizeof(int32_t) * (size_t)F.n_fit);
@@ -1823,6 +1998,7 @@ HOPE_API int hope_get_labels(hope_ctx* c, int frame, int32_t* labels)
 
 HOPE_API int hope_get_clusters(hope_ctx* c, int frame, hope_cluster* out, int cap)
 {
+  ROUTE(c, frame, hope_get_clusters(kid__, local__, out, cap));
   GET_FRAME(c, frame);
   if (!out && cap > 0) return HOPE_E_INVALID;
   const int n = std::min(cap, F.n_clusters);
@@ -1832,6 +2008,7 @@ HOPE_API int hope_get_clusters(hope_ctx* c, int frame, hope_cluster* out, int ca
 
 HOPE_API int hope_get_cluster_indices(hope_ctx* c, int frame, int cluster, int32_t* idx, int cap)
 {
+  ROUTE(c, frame, hope_get_cluster_indices(kid__, local__, cluster, idx, cap));
   GET_FRAME(c, frame);
   if (cluster < 0 || cluster >= F.n_clusters) return HOPE_E_RANGE;
   const ClusterRec& r = c->h_rec[F.cl_start + cluster];
@@ -1847,10 +2024,22 @@ HOPE_API int hope_get_cluster_indices(hope_ctx* c, int frame, int cluster, int32
 
 HOPE_API int hope_get_max_plane(hope_ctx* c, int frame, hope_max_plane* out)
 {
+  ROUTE(c, frame, hope_get_max_plane(kid__, local__, out));
   GET_FRAME(c, frame);
   if (!out) return HOPE_E_INVALID;
   *out = c->h_max[frame];
   return HOPE_OK;
+}
+
+HOPE_API int hope_get_max_plane_members(hope_ctx* c, int frame, int32_t* out, int cap)
+{
+  ROUTE(c, frame, hope_get_max_plane_members(kid__, local__, out, cap));
+  GET_FRAME(c, frame);
+  if (!out && cap > 0) return HOPE_E_INVALID;
+  const std::vector<int32_t>& mem = c->h_max_members[frame];
+  const int n = std::min<int>(cap < 0 ? 0 : cap, (int)mem.size());
+  for (int i = 0; i < n; ++i) out[i] = mem[i];
+  return (int)mem.size();
 }
 
 HOPE_API int hope_profile_enable(hope_ctx* c, int on)
@@ -1862,10 +2051,15 @@ HOPE_API int hope_profile_enable(hope_ctx* c, int on)
     c->prof.bytes[i] = 0;
     c->prof.launches[i] = 0;
   }
+  for (hope_ctx* k : c->kids) hope_profile_enable(k, on);
   return HOPE_OK;
 }
 
-HOPE_API int hope_fast_division_active(const hope_ctx* c) { return c ? c->fast_div : HOPE_E_INVALID; }
+HOPE_API int hope_fast_division_active(const hope_ctx* c)
+{
+  if (!c) return HOPE_E_INVALID;
+  return c->kid_first.empty() ? c->fast_div : c->kids[0]->fast_div;
+}
 
 HOPE_API int hope_profile_stage_count(void) { return ST_COUNT; }
 
@@ -1873,8 +2067,15 @@ HOPE_API int hope_profile_stage(hope_ctx* c, int stage, const char** name, doubl
 {
   if (!c || stage < 0 || stage >= ST_COUNT) return HOPE_E_RANGE;
   if (name) *name = kStageNames[stage];
-  if (total_ms) *total_ms = c->prof.ms[stage];
-  if (launches) *launches = c->prof.launches[stage];
+  // (sub-batches: the regions of every kid; they overlap in time, so their sum exceeds the wall time)
+  double ms = c->prof.ms[stage];
+  long long n = c->prof.launches[stage];
+  for (const hope_ctx* k : c->kids) {
+    ms += k->prof.ms[stage];
+    n += k->prof.launches[stage];
+  }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = n;
   return HOPE_OK;
 }
 
@@ -1882,6 +2083,7 @@ HOPE_API int hope_profile_stage_bytes(hope_ctx* c, int stage, double* alg_bytes)
 {
   if (!c || stage < 0 || stage >= ST_COUNT || !alg_bytes) return HOPE_E_RANGE;
   *alg_bytes = c->prof.bytes[stage];
+  for (const hope_ctx* k : c->kids) *alg_bytes += k->prof.bytes[stage];
   return HOPE_OK;
 }
 

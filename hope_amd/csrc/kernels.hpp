@@ -1889,18 +1889,56 @@ constexpr int kVLoaders = kBlock - kWave;         // 192 loader threads
 constexpr int kVPer = kVTile / kVLoaders;         // 6 members per loader thread per tile
 constexpr int kVStride = kVTile + 4;              // LDS row stride: the 6 chain lanes hit different banks
 
+// acc + sv[0] + sv[1] + ... in that order.  The adds are one dependent chain (4 cycles each); the LDS
+// reads that feed it are issued a whole block (32 values, 8 x 16 bytes) ahead, so the chain never waits
+// for a read it has just issued: a plain "read 16, add 16" loop costs a read latency per block on top of
+// the adds (measured 4.2 ns per add against the 1.7 ns of the add itself).
+__device__ __forceinline__ void chain_load(const float* p, float4 (&r)[8], float& acc)
+{
+#pragma unroll
+  for (int q = 0; q < 8; ++q) r[q] = *reinterpret_cast<const float4*>(p + 4 * q);
+  // the reads are issued in front of the adds they overlap with: the running sum passes through this
+  // statement, so no add moves above it, and no read moves below it
+  asm volatile("" : "+v"(acc) : : "memory");
+}
+__device__ __forceinline__ float chain_add(const float4 (&r)[8], float acc)
+{
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    acc += r[q].x; acc += r[q].y; acc += r[q].z; acc += r[q].w;
+  }
+  return acc;
+}
 __device__ __forceinline__ float chain_sum(const float* sv, int n, float acc)
 {
+  constexpr int kB = 32;
   int j = 0;
-  for (; j + 16 <= n; j += 16) {
+  if (n >= kB) {
+    float4 ra[8], rb[8];  // two register sets, no copies: while one is added the other is in flight
+    chain_load(sv, ra, acc);
+    while (true) {
+      // ra holds [j, j + kB)
+      if (j + 2 * kB > n) {
+        acc = chain_add(ra, acc);
+        j += kB;
+        break;
+      }
+      chain_load(sv + j + kB, rb, acc);
+      acc = chain_add(ra, acc);
+      j += kB;
+      if (j + 2 * kB > n) {
+        acc = chain_add(rb, acc);
+        j += kB;
+        break;
+      }
+      chain_load(sv + j + kB, ra, acc);
+      acc = chain_add(rb, acc);
+      j += kB;
+    }
+  }
+  for (; j + 4 <= n; j += 4) {
     const float4 a = *reinterpret_cast<const float4*>(sv + j);
-    const float4 b = *reinterpret_cast<const float4*>(sv + j + 4);
-    const float4 c = *reinterpret_cast<const float4*>(sv + j + 8);
-    const float4 d = *reinterpret_cast<const float4*>(sv + j + 12);
     acc += a.x; acc += a.y; acc += a.z; acc += a.w;
-    acc += b.x; acc += b.y; acc += b.z; acc += b.w;
-    acc += c.x; acc += c.y; acc += c.z; acc += c.w;
-    acc += d.x; acc += d.y; acc += d.z; acc += d.w;
   }
   for (; j < n; ++j) acc += sv[j];
   return acc;

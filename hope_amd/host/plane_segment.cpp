@@ -209,8 +209,10 @@ void PlaneSegmentRT::getHorizontalPlanes()
   if (st == HOPE_OK && hope_frame_counts(ctx_, 0, &c) >= 0 && hope_get_max_plane(ctx_, 0, &mp) >= 0 && mp.valid) {
     FrameArrays fa;
     if (!fa.load(ctx_, 0, c)) return;
+    std::vector<int32_t> members((size_t)std::max(mp.n_members, 1));   // (every merged cluster: upstream has no limit)
+    if (hope_get_max_plane_members(ctx_, 0, members.data(), mp.n_members) != mp.n_members) return;
     for (int m = 0; m < mp.n_members; ++m)                          // combineCloud order, :943-955 / utilities.cpp:1717-1727
-      if (!fa.cluster_cloud(ctx_, 0, mp.members[m], *max_plane_cloud_, true)) return;
+      if (!fa.cluster_cloud(ctx_, 0, members[m], *max_plane_cloud_, true)) return;
     max_plane_z_ = mp.z;                                            // :958
     max_plane_area_ = computeHull(*max_plane_cloud_, *max_plane_contour_);   // :957
   }

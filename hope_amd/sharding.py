@@ -74,6 +74,16 @@ def _ptr(t):
     return t.data_ptr(), t.is_cuda
 
 
+def _sync(t):
+    """The library runs on a non-blocking stream of its own and requires a device input to be complete
+    before the call (include/hope_gpu.h).  torch's collectives, torch.cat and slice copies only order
+    torch's stream and never block the host, so every tensor they produce is synchronised here before
+    its pointer goes into the library.  No-op for host tensors (gloo)."""
+    if t.is_cuda:
+        import torch
+        torch.cuda.current_stream(t.device).synchronize()
+
+
 def _all_gather_rows(mine, sizes, dist):
     """All-gather of row blocks of different lengths (padded to the longest), concatenated in rank order."""
     import torch
@@ -98,6 +108,7 @@ def segment_cloud_sharded(ctx, xyz_local, dist, apply_filter_transform=False):
     dev = xyz_local.device
     n = xyz_local.shape[0]
     ptr, on_dev = _ptr(xyz_local)
+    _sync(xyz_local)
     # 1. bounding box (MIN/MAX as one MAX over [-min, max]) and survivor count
     bbox, n_raw = ctx.shard_bbox(ptr, n, 12, apply_filter_transform, on_dev)
     mm = torch.tensor(np.concatenate([-bbox[:3], bbox[3:]]), dtype=torch.float32, device=dev)
@@ -128,6 +139,7 @@ def segment_cloud_sharded(ctx, xyz_local, dist, apply_filter_transform=False):
     dist.all_to_all_single(mine[:sum(recv_l)].view(-1), routed[:n_raw].view(-1), [3 * v for v in recv_l],
                            [3 * v for v in send_l])
     # 4. VoxelGrid on the band with the global grid; gather the down-sampled cloud
+    _sync(mine)
     ctx.downsample_cloud_bbox(mine.data_ptr(), sum(recv_l), 12, mine.is_cuda, gbbox)
     vox_local = torch.empty((int(ctx.counts(0).n_vox), 3), dtype=torch.float32, device=dev)
     if vox_local.shape[0]:
@@ -145,6 +157,7 @@ def segment_cloud_sharded(ctx, xyz_local, dist, apply_filter_transform=False):
     # 5. A6..A12 on the whole down-sampled cloud; the two neighbour searches (A6, A8) are shared by z band:
     #    every rank holds all points, so its own band (a contiguous index range) needs no halo
     n_vox = int(vox_all.shape[0])
+    _sync(vox_all)
     if n_vox == 0:
         ctx.segment_cloud(np.zeros((0, 3), np.float32))
         return {"n_raw_total": n_raw_total, "n_vox": 0, "sent": send_l, "received": recv_l, "bands": owner}
@@ -157,6 +170,7 @@ def segment_cloud_sharded(ctx, xyz_local, dist, apply_filter_transform=False):
     own_n = torch.empty((count, 4), dtype=torch.float32, device=dev)   # written by the library, host or device
     ctx.normals_rows(first, count, out_ptr=own_n.data_ptr(), out_on_device=own_n.is_cuda)
     normals_all = _all_gather_rows(own_n, sizes_l, dist)
+    _sync(normals_all)
     ctx.segment_downsampled_staged(*args, normals_ptr=normals_all.data_ptr(), stop_after=2)
     fit_idx = ctx.fit_indices(0)
     lo, hi = (int(v) for v in np.searchsorted(fit_idx, [first, first + count]))
@@ -170,6 +184,7 @@ def segment_cloud_sharded(ctx, xyz_local, dist, apply_filter_transform=False):
         own_k = torch.empty((hi - lo, ctx.cfg.knn), dtype=torch.int32, device=dev)
         ctx.knn_rows(lo, hi - lo, out_ptr=own_k.data_ptr(), out_on_device=own_k.is_cuda)
         knn_all = _all_gather_rows(own_k, fit_sizes_l, dist)
+    _sync(knn_all)
     ctx.segment_downsampled_staged(*args, normals_ptr=normals_all.data_ptr(), knn_ptr=knn_all.data_ptr(), stop_after=0)
     return {"n_raw_total": n_raw_total, "n_vox": n_vox, "n_fit": sum(fit_sizes_l), "sent": send_l, "received": recv_l,
             "bands": owner, "own_vox": sizes_l, "own_fit": fit_sizes_l}

@@ -111,8 +111,10 @@ typedef struct hope_max_plane {
   int32_t valid;          /* 0: no plane inside the height window                    */
   int32_t n_points;       /* max_plane_points_num_ (merged count when aggressive)    */
   float z;                /* max_plane_z_                                            */
-  int32_t n_members;      /* number of clusters whose points form max_plane_cloud_   */
-  int32_t members[16];    /* their cluster indices, in max_plane_cloud_ point order  */
+  int32_t n_members;      /* number of clusters whose points form max_plane_cloud_ (no limit:
+                             plane_segment.cpp:943-955 concatenates every merged cluster)      */
+  int32_t members[16];    /* the first min(n_members, 16) of them, in max_plane_cloud_ point
+                             order; the whole list: hope_get_max_plane_members               */
 } hope_max_plane;
 
 /* ---- lifecycle ------------------------------------------------------------------- */
@@ -171,6 +173,10 @@ HOPE_API int hope_get_cluster_indices(hope_ctx* ctx, int frame, int cluster, int
                                       int cap);
 /* PlaneSegmentRT::max_plane_* */
 HOPE_API int hope_get_max_plane(hope_ctx* ctx, int frame, hope_max_plane* out);
+/* every cluster whose points form max_plane_cloud_ (plane_segment.cpp:943-955: combineCloud puts the
+ * new cluster in front of the old max plane, utilities.cpp:1717-1727), in point order: writes
+ * min(cap, n_members) cluster indices and returns n_members */
+HOPE_API int hope_get_max_plane_members(hope_ctx* ctx, int frame, int32_t* out, int cap);
 /* wall-clock of the last segment call in ms: whole path, and the reference's own timer
  * window (findAllPlanes only, plane_segment.cpp:157-169) */
 HOPE_API int hope_last_timing(hope_ctx* ctx, double* whole_ms, double* ref_window_ms);

@@ -80,6 +80,7 @@ struct Frame {
   std::vector<int> labels;                 // per fit point -> cluster (filtered) or -1
   std::vector<Cluster> clusters;           // A9..A12
   hope_max_plane max_plane;
+  std::vector<int> max_members;            // every cluster of max_plane_cloud_, in point order (no limit)
 };
 
 }  // namespace
@@ -791,6 +792,7 @@ void run_frame_after_transform(hope_ctx* c, Frame& f, double& ref_ms)
   f.max_plane.n_points = 0;
   f.max_plane.z = -1000.0f;
   f.max_plane.n_members = 0;
+  f.max_members.clear();
   for (size_t ci = 0; ci < f.clusters.size(); ++ci) {
     Cluster& cl = f.clusters[ci];
     float mid = 0.0f;
@@ -829,7 +831,7 @@ void run_frame_after_transform(hope_ctx* c, Frame& f, double& ref_ms)
         int count = (int)cl.indices.size();
         if (c->cfg.aggressive_merge && f.max_plane.valid) {
           if (std::fabs(f.max_plane.z - z_in) <= c->cfg.th_z) {
-            for (int m = 0; m < f.max_plane.n_members; ++m) members.push_back(f.max_plane.members[m]);
+            members.insert(members.end(), f.max_members.begin(), f.max_members.end());
             count += f.max_plane.n_points;
           }
         }
@@ -837,8 +839,9 @@ void run_frame_after_transform(hope_ctx* c, Frame& f, double& ref_ms)
           f.max_plane.valid = 1;
           f.max_plane.n_points = count;
           f.max_plane.z = z_in;
-          f.max_plane.n_members = (int)std::min<size_t>(members.size(), 16);
-          for (int m = 0; m < f.max_plane.n_members; ++m) f.max_plane.members[m] = members[m];
+          f.max_members = members;  // plane_segment.cpp:943-955 concatenates without limit
+          f.max_plane.n_members = (int)members.size();
+          for (size_t m = 0; m < members.size() && m < 16; ++m) f.max_plane.members[m] = members[m];
         }
       }
     }
@@ -1457,6 +1460,15 @@ ORACLE_API int hope_oracle_get_max_plane(hope_ctx* ctx, int frame, hope_max_plan
   if (!out) return HOPE_E_INVALID;
   *out = f.max_plane;
   return HOPE_OK;
+}
+
+ORACLE_API int hope_oracle_get_max_plane_members(hope_ctx* ctx, int frame, int32_t* out, int cap)
+{
+  GET_FRAME(ctx, frame);
+  if (!out && cap > 0) return HOPE_E_INVALID;
+  const int n = std::min<int>(cap < 0 ? 0 : cap, (int)f.max_members.size());
+  for (int i = 0; i < n; ++i) out[i] = f.max_members[i];
+  return (int)f.max_members.size();
 }
 
 ORACLE_API int hope_oracle_last_timing(hope_ctx* ctx, double* whole_ms, double* ref_ms)

@@ -56,3 +56,18 @@ def synth_frames(n, first=0):
     from hope_amd import synth
     d, t, q = synth.make_depth_frames(n, first_frame=first, device="cpu")
     return d.numpy().view(np.uint16), t.numpy(), q.numpy()
+
+
+def patch_cloud(n_patches=24, per_patch=3000, seed=3):
+    """n_patches separate horizontal patches (0.6 m squares, 1.5 m apart) at z = 1 m +- 2 mm noise, in the
+    sensor frame of an identity pose: one ZGrowing cluster each, all within th_z of one height, so the
+    RT winner merges every one of them (plane_segment.cpp:943-955 has no limit on that)."""
+    rng = np.random.default_rng(seed)
+    pts = []
+    for k in range(n_patches):
+        ox, oy = 1.5 * (k % 6) - 3.75, 1.5 * (k // 6) - 2.25
+        xy = rng.uniform(0.0, 0.6, (per_patch, 2)).astype(np.float32) + np.array([ox, oy], np.float32)
+        z = (1.0 + rng.normal(0.0, 0.002, per_patch)).astype(np.float32)
+        pts.append(np.concatenate([xy, z[:, None]], 1))
+    xyz = np.concatenate(pts).astype(np.float32)
+    return xyz[rng.permutation(len(xyz))]

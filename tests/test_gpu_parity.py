@@ -132,8 +132,30 @@ def test_rt_mode_and_height_window(hip_lib, oracle_lib):
     g.set_height_window(0.6, 0.9)
     g.segment_depth(z["depth"])
     m = g.max_plane(0)
-    assert {"valid": m.valid, "n_points": m.n_points, "z": float(m.z), "members": list(m.members)[:m.n_members],
+    assert {"valid": m.valid, "n_points": m.n_points, "z": float(m.z), "members": g.max_plane_members(0),
             "n_planes": g.counts(0).n_planes} == gold
+
+
+def test_rt_winner_merges_more_than_sixteen_clusters(hip_lib, oracle_lib, tmp_path):
+    """plane_segment.cpp:943-960: no limit on the clusters merged into the max plane.  24 patches at one
+    height: the member list, the point count and the adapter's max_plane_cloud_ hold all of them."""
+    import json
+    import subprocess
+    from conftest import patch_cloud
+    xyz = patch_cloud(24)
+    g, o = both(hip_lib, oracle_lib, mode=HOPE_MODE_RT, min_height=0.8, max_height=1.5, aggressive_merge=1)
+    for c in (g, o):
+        assert c.segment_cloud(xyz, apply_filter_transform=True) == 0
+    assert_frame_equal(o, g, 0)
+    m, mem = g.max_plane(0), g.max_plane_members(0)
+    cl = g.clusters(0)
+    assert m.n_members == len(mem) >= 20 and m.n_points == sum(int(cl["size"][i]) for i in mem)
+    rt = os.path.join(ROOT, "tests", "_build", "rt_driver_hip")
+    f = tmp_path / "patches.f32"
+    xyz.tofile(f)
+    r = subprocess.run([rt, str(f), "0", "0", "0", "0", "0", "0", "1", "0.8", "1.5", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout.strip().splitlines()[-1])["points"] == m.n_points   # max_plane_cloud_->size()
 
 
 def test_edge_cases(hip_lib, oracle_lib):
@@ -495,6 +517,51 @@ def test_invalid_arguments(hip_lib):
     assert b"range" in hip_lib.fn["last_error"](g._h)
 
 
+def test_sub_batches_on_their_own_streams(hip_lib, oracle_lib, monkeypatch):
+    """A batch of many frames runs as up to four frame ranges, each in a child context with its own stream,
+    workspace and host thread (hope_hip.hip: segment_depth_split).  Forced here on 14 frames (ranges of 3-4):
+    every stage of every frame equals the oracle's, the per-frame accessors and the objects-on-plane step find
+    their frame in the right range, and a later small call leaves the split state behind."""
+    from test_upon_plane import winner_contour
+    import ctypes
+    depth, t, q = synth_frames(14, first=40)
+    monkeypatch.setenv("HOPE_DEBUG_SUB_MIN", "3")
+    g = HopeContext(hip_lib, mode=HOPE_MODE_RT, min_height=0.5, max_height=1.0)
+    monkeypatch.delenv("HOPE_DEBUG_SUB_MIN")
+    o = HopeContext(oracle_lib, mode=HOPE_MODE_RT, min_height=0.5, max_height=1.0)
+    for c in (g, o):
+        c.set_frame_poses(t, q)
+        assert c.segment_depth(depth) == 0
+        assert c.num_frames() == 14
+    for f in range(14):
+        assert_frame_equal(o, g, f, check_transformed=(f in (3, 4, 13)))
+    host = ctypes.CDLL(os.path.join(ROOT, "hope_amd", "host", "libhope_host.so"))
+    for f in (0, 6, 13):
+        if not o.max_plane(f).valid:
+            continue
+        contour = winner_contour(o, host, f)
+        na, ca = o.clusters_upon_plane(contour, frame=f)
+        nb, cb = g.clusters_upon_plane(contour, frame=f)
+        assert na == nb and len(ca) == len(cb)
+        for (xa, ia), (xb, ib) in zip(ca, cb):
+            assert np.array_equal(ia, ib) and xa.tobytes() == xb.tobytes()
+    from hope_amd.capi import HopeCounts
+    cnt = HopeCounts()
+    assert hip_lib.fn["frame_counts"](g._h, 14, ctypes.byref(cnt)) < 0
+    # the same pose for every frame (hope_set_pose) reaches the ranges too
+    for c in (g, o):
+        c.set_pose(t[5], q[5])
+        c.segment_depth(depth)
+    for f in (0, 5, 13):
+        assert_frame_equal(o, g, f)
+    # a small call afterwards is not split
+    for c in (g, o):
+        c.set_frame_poses(t[:2], q[:2])
+        c.segment_depth(depth[:2])
+        assert c.num_frames() == 2
+    assert_frame_equal(o, g, 1)
+
+
 def test_full_size_batch_properties(hip_lib, oracle_lib):
     """BASELINE.json configs[1] at full size (1024 frames generated on the device): the oracle cannot
     run all of it in seconds, so check size-independent properties plus exact parity on sampled frames."""
@@ -519,7 +586,9 @@ def test_full_size_batch_properties(hip_lib, oracle_lib):
         assert c.n_raw == valid[f]                      # 0.3 < d/5000 < 8.0  <=>  1500 < d < 40000
         assert 0 < c.n_fit <= c.n_vox <= c.n_raw
         assert c.n_planes <= c.n_clusters <= c.n_segments <= c.n_fit
-    sample = [0, 333, 1023]
+    # 36 frames: every 31st, plus both sides of every sub-batch boundary (the batch runs as four ranges of
+    # 256 frames, each on a stream and host thread of its own)
+    sample = sorted(set(list(range(0, F, 31)) + [255, 256, 511, 512, 767, 768, 1023]))
     digests = {f: summary(g, f) for f in sample}
     labels = {f: g.labels(f) for f in sample}
     for f in sample:

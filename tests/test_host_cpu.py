@@ -371,9 +371,26 @@ def test_rt_adapter(test_bins, oracle_lib, tum_example, tmp_path):
         assert got["points"] == m.n_points and np.float32(got["z"]) == np.float32(m.z)
         vox, fit = c.downsampled(0), c.fit_indices(0)
         cl = c.clusters(0)
-        pts = np.concatenate([vox[fit[c.cluster_indices(0, ci, int(cl["size"][ci]))]] for ci in list(m.members)[:m.n_members]])
+        pts = np.concatenate([vox[fit[c.cluster_indices(0, ci, int(cl["size"][ci]))]] for ci in c.max_plane_members(0)])
         from scipy.spatial import ConvexHull
         ref = ConvexHull(pts[:, :2].astype(np.float64))
         contour = np.array(got["contour"], np.float32)
         assert sorted(map(tuple, contour)) == sorted(map(tuple, pts[ref.vertices]))
         assert abs(got["area"] - ref.volume) < 1e-6
+
+
+def test_rt_adapter_merges_every_cluster_of_one_height(test_bins, oracle_lib, tmp_path):
+    """max_plane_cloud_ holds the points of ALL merged clusters (plane_segment.cpp:943-960), also beyond
+    sixteen of them: its size is the winner's point count."""
+    from conftest import patch_cloud
+    xyz = patch_cloud(24)
+    f = tmp_path / "patches.f32"
+    xyz.tofile(f)
+    r = subprocess.run([test_bins[1], str(f), "0", "0", "0", "0", "0", "0", "1", "0.8", "1.5", "1"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    c = HopeContext(oracle_lib, mode=HOPE_MODE_RT, min_height=0.8, max_height=1.5, aggressive_merge=1)
+    c.segment_cloud(xyz, apply_filter_transform=True)
+    m = c.max_plane(0)
+    assert m.n_members >= 20 and got["points"] == m.n_points

@@ -77,7 +77,7 @@ def test_against_committed_golden(oracle_lib, tum_example):
     c3.set_frame_poses(z["t"], z["q"])
     c3.segment_depth(z["depth"])
     m = c3.max_plane(0)
-    assert {"valid": m.valid, "n_points": m.n_points, "z": float(m.z), "members": list(m.members)[:m.n_members],
+    assert {"valid": m.valid, "n_points": m.n_points, "z": float(m.z), "members": c3.max_plane_members(0),
             "n_planes": c3.counts(0).n_planes} == g["rt_frame0"]
 
 
@@ -145,8 +145,8 @@ def test_rt_height_window_and_merge(oracle_lib):
     assert m.valid == 1 and 0.6 < m.z < 0.9
     inside = [i for i in range(len(cl)) if cl["pass"][i] and 0.6 < cl["z_mean"][i] < 0.9]
     assert c.counts(0).n_planes == len(inside)
-    assert set(list(m.members)[:m.n_members]) <= set(inside)
-    assert m.n_points == sum(int(cl["size"][i]) for i in list(m.members)[:m.n_members])
+    assert set(c.max_plane_members(0)) <= set(inside)
+    assert m.n_points == sum(int(cl["size"][i]) for i in c.max_plane_members(0))
     # dynamic reconfigure analogue: move the window to the floor
     c.set_height_window(-0.1, 0.3)
     c.segment_depth(z["depth"])
@@ -155,6 +155,28 @@ def test_rt_height_window_and_merge(oracle_lib):
     c.set_height_window(3.0, 4.0)
     c.segment_depth(z["depth"])
     assert c.max_plane(0).valid == 0
+
+
+def test_rt_winner_merges_more_than_sixteen_clusters(oracle_lib):
+    """plane_segment.cpp:943-960: every passing cluster within th_z of the current max plane is merged into
+    it, however many there are; the winner's member list and point count are those of all of them."""
+    from conftest import patch_cloud
+    xyz = patch_cloud(24)
+    c = HopeContext(oracle_lib, mode=HOPE_MODE_RT, min_height=0.8, max_height=1.5, aggressive_merge=1)
+    c.segment_cloud(xyz, apply_filter_transform=True)
+    cl = c.clusters(0)
+    m = c.max_plane(0)
+    mem = c.max_plane_members(0)
+    passing = [i for i in range(len(cl)) if cl["pass"][i] and 0.8 < cl["z_mean"][i] < 1.5]
+    assert len(passing) >= 20 and m.valid == 1
+    assert m.n_members == len(mem) == len(passing)               # all at one height: all merged
+    assert mem == passing[::-1]                                  # combineCloud: newest cluster first
+    assert m.n_points == sum(int(cl["size"][i]) for i in mem)
+    assert list(m.members) == mem[:16]
+    # without the merge the winner is the largest single cluster
+    c2 = HopeContext(oracle_lib, mode=HOPE_MODE_RT, min_height=0.8, max_height=1.5, aggressive_merge=0)
+    c2.segment_cloud(xyz, apply_filter_transform=True)
+    assert c2.max_plane(0).n_members == 1 and c2.max_plane(0).n_points == max(int(cl["size"][i]) for i in passing)
 
 
 def test_voxelgrid_leaf_too_small_passes_the_input_through(oracle_lib):

@@ -17,7 +17,7 @@ def winner_contour(ctx, host_lib, frame=0):
     m = ctx.max_plane(frame)
     assert m.valid
     vox, fit, cl = ctx.downsampled(frame), ctx.fit_indices(frame), ctx.clusters(frame)
-    pts = np.concatenate([vox[fit[ctx.cluster_indices(frame, ci, int(cl["size"][ci]))]] for ci in list(m.members)[:m.n_members]])
+    pts = np.concatenate([vox[fit[ctx.cluster_indices(frame, ci, int(cl["size"][ci]))]] for ci in ctx.max_plane_members(frame)])
     idx, _ = hull(host_lib, pts)
     return pts[idx]
 
