@@ -17,6 +17,7 @@
 #include "neighbours.hpp"
 #include "prims.hpp"
 #include "upon_plane.hpp"
+#include "voxel_rank.hpp"
 
 using namespace hope;
 
@@ -106,11 +107,11 @@ inline unsigned nblk(size_t n, int per = kBlock) { return (unsigned)((n + per - 
 // Optional per-stage timing with HIP events recorded on the ctx stream (bench.py's roofline
 // figures come from here; off by default).
 enum Stage {
-  ST_BBOX, ST_GRID, ST_VKEYS, ST_VSORT, ST_VRLE, ST_CENTROID, ST_COLKEYS, ST_COLSORT, ST_COLTABLE, ST_NORMALS,
+  ST_BBOX, ST_GRID, ST_VKEYS, ST_VSORT, ST_VRLE, ST_VRANK, ST_CENTROID, ST_COLKEYS, ST_COLSORT, ST_COLTABLE, ST_NORMALS,
   ST_FIT, ST_FITIDX, ST_KNN, ST_KNN_TODO, ST_LABELS, ST_SEGMENTS, ST_VERIFY, ST_COUNT
 };
 const char* const kStageNames[ST_COUNT] = {
-  "k_bbox", "k_frame_grid", "k_voxel_keys", "voxel_sort(rocprim)", "voxel_rle+scan(rocprim)", "k_centroids",
+  "k_bbox", "k_frame_grid", "k_voxel_keys", "voxel_sort(rocprim)", "voxel_rle+scan(rocprim)", "k_voxel_rank", "k_centroids",
   "k_column_keys", "column_sort(rocprim)", "k_column_table+gather", "k_normals", "fit_gate+compact", "fit_column_index", "k_knn",
   "k_knn_todo",
   "labels(union+sweeps)", "segments(scan+sort)", "k_cluster_verify"};
@@ -170,6 +171,8 @@ struct hope_ctx {
   int pixel_sort = 0;         // test knob: depth frames through the per-pixel sort (the cloud path's voxel stage)
   int col_sort_z = 0;         // test knob HOPE_DEBUG_COLSORT_Z=1: z cell bits in the column sort key even for VoxelGrid output
   int seg_sort = 1;           // per-frame segmented sort of the group records (HOPE_DEBUG_SEGSORT=0: device-wide sort)
+  int voxel_rank = 1;         // depth batches: voxels ranked by an LDS bitmap per frame instead of sorting the group
+                              // records (HOPE_DEBUG_VOXEL_RANK=0, or any knob that asks for a sort: the sorting path)
   uint32_t* d_grp_cnt = nullptr;  // depth path: groups per chunk, then its exclusive scan
   uint32_t* d_grp_off = nullptr;
   unsigned cpf = 0;               // chunks per frame
@@ -211,7 +214,8 @@ struct hope_ctx {
   // by a child context of its own (own stream, own workspace) on a host thread of its own: while one
   // range waits for a count to come back or runs a kernel that cannot fill the chip (a chain of
   // dependent adds, one workgroup per frame), the kernels of the other ranges use the idle CUs.
-  int n_sub = 4;                  // HOPE_SUB_BATCHES (1: never split)
+  int n_sub = 1;                  // HOPE_SUB_BATCHES (1: never split).  Measured on MI355X, 1024 frames: four ranges
+                                  // 13.7 ms against 12.3 ms unsplit -- the kernels already fill the chip -- so off by default
   int sub_min_frames = 64;        // HOPE_DEBUG_SUB_MIN: frames per range below which a batch is not cut further
   std::vector<hope_ctx*> kids;
   std::vector<int> kid_first;     // last call: kid k holds frames [kid_first[k], kid_first[k+1]); empty: not split
@@ -486,6 +490,47 @@ void launch_centroids_groups(hope_ctx*, const CloudSrc&, const VK*, const uint32
 inline double src_point_bytes(const DepthSrc&) { return 2.0; }
 inline double src_point_bytes(const CloudSrc&) { return 12.0; }
 
+// A5 for depth batches without a sort (voxel_rank.hpp): the voxels of every frame ranked by an LDS bitmap of
+// its occupied cells, from k_group_keys' dense (cell, slot) pairs.
+int stage_voxel_rank(hope_ctx* c, const DepthSrc& src, size_t n_per_frame, size_t M, int cell_bits, const uint32_t* keys,
+                     const uint32_t* vals, float4*& d_vox, int*& d_vox_frame)
+{
+  const int F = c->n_frames;
+  hipStream_t s = c->stream;
+  uint32_t *rec_vox, *rec_list, *vox_end, *vox_cnt, *block_first;
+  ALLOC(block_first, uint32_t, (size_t)F + 1);
+  ALLOC(rec_vox, uint32_t, M);
+  ALLOC(rec_list, uint32_t, M);
+  ALLOC(vox_end, uint32_t, M);
+  ALLOC(vox_cnt, uint32_t, (size_t)F);
+  size_t pm = prof_mark(c);
+  hipLaunchKernelGGL(k_voxel_rank, dim3(F), dim3(kRankBlock), 0, s, c->d_fi, c->cpf, c->d_grp_off, keys, vals,
+                     (cell_bits >= 32 ? 0xffffffffu : ((1u << cell_bits) - 1u)), rec_vox, rec_list, vox_end, vox_cnt);
+  hipLaunchKernelGGL(k_frame_vox_scan, dim3(1), dim3(kRankBlock), 0, s, c->d_fi, F, vox_cnt, block_first, c->d_glob);
+  prof_close(c, ST_VRANK, pm, (8.0 + 4.0 + 4.0) * M);
+  int st = sync_globals(c);
+  if (st != HOPE_OK) return st;
+  const unsigned n_vox = c->h_glob->n_vox_total;
+  c->n_vox_total = n_vox;
+  if (n_vox == 0) return HOPE_OK;
+  ALLOC(d_vox, float4, n_vox);
+  ALLOC(d_vox_frame, int, n_vox);
+  pm = prof_mark(c);
+  const dim3 grid(c->h_glob->max_vox);  // (blocks of kBlock voxels, frame by frame)
+  if (c->fast_div)
+    hipLaunchKernelGGL(k_centroids_lists<true>, grid, dim3(kBlock), 0, s, src, c->d_fi, F, block_first, c->cpf,
+                       c->d_grp_off, rec_list, vox_end, c->d_slots, d_vox, d_vox_frame);
+  else
+    hipLaunchKernelGGL(k_centroids_lists<false>, grid, dim3(kBlock), 0, s, src, c->d_fi, F, block_first, c->cpf,
+                       c->d_grp_off, rec_list, vox_end, c->d_slots, d_vox, d_vox_frame);
+  prof_close(c, ST_CENTROID, pm, (4.0 + 16.0) * M + 2.0 * (double)n_per_frame * F + (28.0 + 4.0) * n_vox);
+  return HOPE_OK;
+}
+int stage_voxel_rank(hope_ctx*, const CloudSrc&, size_t, size_t, int, const uint32_t*, const uint32_t*, float4*&, int*&)
+{
+  return HOPE_E_INVALID;  // (never called: clouds do not take the group path)
+}
+
 // A5.  Two ways to bring the points of a voxel together in ascending source index:
 //  * depth frames: sort one record per (64-pixel chunk, voxel) group (k_bbox_groups has already
 //    counted them, scan_groups placed them);
@@ -518,6 +563,10 @@ int stage_voxel(hope_ctx* c, const Src& src, size_t n_per_frame, int cell_bits, 
     hipLaunchKernelGGL((k_group_keys<VK>), dim3(nblk(n_chunks * 8)), dim3(kBlock), 0, s, c->d_fi, c->inv_xy, c->inv_z,
                        cell_bits, c->cpf, (unsigned)n_chunks, c->d_grp_off, c->d_slots, k_in, v_in);
     prof_close(c, ST_VKEYS, pm, 8.0 * ((double)c->cpf * F) + (4.0 + sizeof(VK) + 4.0) * M);
+    // no sort: the voxels of a frame ranked by an LDS bitmap of its occupied cells (grids beyond 2^24 cells,
+    // 16 cell ranges, and 64-bit keys take the sorting path)
+    if (c->voxel_rank && sizeof(VK) == 4 && c->h_glob->max_cells <= (1ull << 24))
+      return stage_voxel_rank(c, src, n_per_frame, M, cell_bits, (const uint32_t*)k_in, v_in, d_vox, d_vox_frame);
   } else if (groups) {
     // two passes: by choice, or because a cell fell outside the code range of k_bbox_records (its counts
     // and bounding box are valid all the same)
@@ -1132,6 +1181,8 @@ HOPE_API int hope_create(const hope_config* cfg, hope_ctx** out)
   if (knob && std::atoi(knob) >= 1) c->sub_min_frames = std::atoi(knob);
   knob = std::getenv("HOPE_DEBUG_SEGSORT");
   c->seg_sort = (knob && knob[0] == '0') ? 0 : 1;
+  knob = std::getenv("HOPE_DEBUG_VOXEL_RANK");
+  c->voxel_rank = (knob && knob[0] == '0') ? 0 : c->seg_sort;
   *out = c;
   return HOPE_OK;
 }

@@ -56,6 +56,8 @@ struct Globals {  // scalars produced on device, read back at the sync points
   unsigned int n_todo;       // k-NN queries left over by the tile pass
   unsigned int max_fit;      // largest per-frame count of fit points
   unsigned int code_overflow;  // k_bbox_records: a cell lies outside the packed code range
+  unsigned int rank_overflow;  // k_voxel_rank: a frame has more voxels than the LDS counters hold
+  unsigned int max_vox;        // k_frame_vox_scan: largest per-frame count of voxels
 };
 
 struct DepthSrc {

@@ -1,0 +1,358 @@
+// voxel_rank.hpp — A5 (pcl::VoxelGrid, utilities.cpp:455-468) for depth batches without a sort.
+//
+// k_bbox_records has left one record per (chunk, voxel) group and k_group_keys the dense (voxel index,
+// record slot) pairs of every frame, in chunk order.  VoxelGrid's output order is ascending voxel index,
+// and a frame's grid has a few hundred thousand to a few million cells: a bitmap of the occupied cells
+// fits in LDS (in one to a few cell ranges), and the rank of a set bit IS the voxel's place in the
+// output.  One 1024-thread workgroup per frame therefore replaces the segmented radix sort of the
+// records, the run-length encoding and the scans around them:
+//   per cell range:   set the bit of every record's cell (LDS atomic OR); popcount scan -> prefix per
+//                     256 bits; voxel of a record = rank of its bit (written next to the record)
+//   per voxel range:  records per voxel (LDS atomic add); scan -> first place of every voxel's records;
+//                     each record takes the next free place of its voxel (returning LDS atomic add)
+// The places inside a voxel come out in arrival order; k_centroids_lists sorts each voxel's few records
+// by slot number (= chunk order: band of rows, then left to right) in LDS before it walks them, which is
+// the order the stable sort used to leave.
+#pragma once
+#include "kernels.hpp"
+
+namespace hope {
+
+constexpr int kRankBlock = 1024;
+
+// exclusive scan of one value per thread over a kRankBlock-thread workgroup; s_w: 17 words of LDS
+__device__ __forceinline__ unsigned block_scan_excl_1024(unsigned v, unsigned* s_w, unsigned& total)
+{
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  unsigned inc = v;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const unsigned t = (unsigned)__shfl_up((int)inc, off);
+    if (lane >= off) inc += t;
+  }
+  __syncthreads();  // (s_w may still be read by the previous scan's callers)
+  if (lane == kWave - 1) s_w[wv] = inc;
+  __syncthreads();
+  if (threadIdx.x < kWave) {
+    const unsigned w = lane < kRankBlock / kWave ? s_w[lane] : 0u;
+    unsigned wi = w;
+#pragma unroll
+    for (int off = 1; off < kRankBlock / kWave; off <<= 1) {
+      const unsigned t = (unsigned)__shfl_up((int)wi, off);
+      if (lane >= off) wi += t;
+    }
+    if (lane < kRankBlock / kWave) s_w[lane] = wi - w;
+    if (lane == kRankBlock / kWave - 1) s_w[kRankBlock / kWave] = wi;
+  }
+  __syncthreads();
+  total = s_w[kRankBlock / kWave];
+  return s_w[wv] + inc - v;
+}
+
+constexpr unsigned kBmWords = 32768;              // bitmap words per cell range: 2^20 cells, 128 KiB
+constexpr unsigned kBmBits = kBmWords * 32u;
+constexpr unsigned kPfxEvery = 8;                 // one prefix entry per 8 bitmap words (two 16-byte LDS reads)
+constexpr unsigned kPfxWords = kBmWords / kPfxEvery;
+constexpr unsigned kRankLds = 40704;              // words of LDS (159 KiB): bitmap + prefix, later the counters
+constexpr unsigned kCntCap = kRankLds;            // voxels per voxel range
+static_assert(kBmWords + kPfxWords <= kRankLds, "bitmap and prefix table share the counters' LDS");
+
+// every record o of [0, n) once: four loads in flight per thread, then body(o, a[o] (, b[o])) for each
+template <class Body>
+__device__ __forceinline__ void for_each_record(unsigned n, const uint32_t* a, Body&& body)
+{
+  for (unsigned base = threadIdx.x; base < n; base += 4u * kRankBlock) {
+    unsigned x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned o = base + (unsigned)u * kRankBlock;
+      x[u] = a[o < n ? o : n - 1u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned o = base + (unsigned)u * kRankBlock;
+      if (o < n) body(o, x[u]);
+    }
+  }
+}
+
+__device__ __forceinline__ unsigned popc4(const uint4& q)
+{
+  return (unsigned)(__popc(q.x) + __popc(q.y) + __popc(q.z) + __popc(q.w));
+}
+
+// grid = n_frames, block = kRankBlock.  keys: cell index of every record (low cell_bits bits of k_group_keys'
+// sort key), vals: its slot; both dense, in emission (chunk) order, the frame's records at
+// [grp_off[f * cpf], grp_off[(f + 1) * cpf]).
+__global__ void __launch_bounds__(kRankBlock)
+k_voxel_rank(const FrameInfo* fi, unsigned cpf, const uint32_t* grp_off, const uint32_t* keys, const uint32_t* vals,
+             unsigned cell_mask, uint32_t* rec_vox, uint32_t* rec_list, uint32_t* vox_end, uint32_t* vox_cnt)
+{
+  __shared__ __attribute__((aligned(16))) unsigned s_mem[kRankLds];
+  __shared__ unsigned s_w[kRankBlock / kWave + 1];
+  unsigned* bitmap = s_mem;             // kBmWords
+  unsigned* prefix = s_mem + kBmWords;  // kPfxWords
+  unsigned* counters = s_mem;           // kCntCap (after the ranks have been written)
+  const int f = blockIdx.x;
+  const unsigned tid = threadIdx.x;
+  const unsigned rec_base = grp_off[(size_t)f * cpf];
+  const unsigned n_rec = grp_off[(size_t)(f + 1) * cpf] - rec_base;
+  if (n_rec == 0u) {
+    if (tid == 0) vox_cnt[f] = 0u;
+    return;
+  }
+  const unsigned cells = (unsigned)fi[f].cells;
+  const uint32_t* key = keys + rec_base;
+  const uint32_t* val = vals + rec_base;
+  uint32_t* rvox = rec_vox + rec_base;
+  const uint4* bm4 = reinterpret_cast<const uint4*>(bitmap);
+  // ---- voxel of every record = rank of its cell among the occupied cells, one cell range at a time ----
+  unsigned n_vox = 0u;
+  for (unsigned lo = 0u; lo < cells; lo += kBmBits) {  // (uniform)
+    const unsigned span = min(kBmBits, cells - lo);
+    const unsigned n_grp = (span + 32u * kPfxEvery - 1u) / (32u * kPfxEvery);  // prefix entries in use
+    for (unsigned i = tid; i < n_grp * kPfxEvery; i += kRankBlock) bitmap[i] = 0u;
+    __syncthreads();
+    for_each_record(n_rec, key, [&](unsigned, unsigned k) {
+      const unsigned idx = (k & cell_mask) - lo;
+      if (idx < span) atomicOr(&bitmap[idx >> 5], 1u << (idx & 31u));
+    });
+    __syncthreads();
+    const unsigned per = (n_grp + kRankBlock - 1) / kRankBlock;
+    unsigned mine = 0u;
+    for (unsigned k = 0; k < per; ++k) {
+      const unsigned gi = tid * per + k;
+      if (gi < n_grp) mine += popc4(bm4[2 * gi]) + popc4(bm4[2 * gi + 1]);
+    }
+    unsigned total;
+    unsigned ex = block_scan_excl_1024(mine, s_w, total);
+    for (unsigned k = 0; k < per; ++k) {
+      const unsigned gi = tid * per + k;
+      if (gi < n_grp) {
+        prefix[gi] = n_vox + ex;
+        ex += popc4(bm4[2 * gi]) + popc4(bm4[2 * gi + 1]);
+      }
+    }
+    __syncthreads();
+    for_each_record(n_rec, key, [&](unsigned o, unsigned k) {
+      const unsigned idx = (k & cell_mask) - lo;
+      if (idx < span) {
+        const unsigned w = idx >> 5, sub = w & 7u;
+        const uint4 qa = bm4[(w >> 3) * 2u], qb = bm4[(w >> 3) * 2u + 1u];
+        const unsigned wd[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+        unsigned r = prefix[w >> 3];
+        unsigned cur = 0u;
+#pragma unroll
+        for (unsigned j = 0; j < 8u; ++j) {
+          r += j < sub ? (unsigned)__popc(wd[j]) : 0u;
+          cur = j == sub ? wd[j] : cur;
+        }
+        rvox[o] = r + (unsigned)__popc(cur & ((1u << (idx & 31u)) - 1u));
+      }
+    });
+    n_vox += total;
+    __syncthreads();  // (the next range clears the bitmap; the counters below reuse it)
+  }
+  // ---- the records of every voxel, one voxel range at a time (counters alias the bitmap) ----------------
+  unsigned list_base = 0u;  // places taken by the voxels of earlier ranges
+  for (unsigned vlo = 0u; vlo < n_vox; vlo += kCntCap) {  // (uniform)
+    const unsigned nv = min(kCntCap, n_vox - vlo);
+    for (unsigned i = tid; i < nv; i += kRankBlock) counters[i] = 0u;
+    __syncthreads();
+    for_each_record(n_rec, rvox, [&](unsigned, unsigned rv) {
+      const unsigned v = rv - vlo;
+      if (v < nv) atomicAdd(&counters[v], 1u);
+    });
+    __syncthreads();
+    const unsigned perv = (nv + kRankBlock - 1) / kRankBlock;
+    unsigned sum = 0u;
+    for (unsigned k = 0; k < perv; ++k) {
+      const unsigned v = tid * perv + k;
+      if (v < nv) sum += counters[v];
+    }
+    unsigned total;
+    unsigned at = list_base + block_scan_excl_1024(sum, s_w, total);
+    for (unsigned k = 0; k < perv; ++k) {
+      const unsigned v = tid * perv + k;
+      if (v < nv) {
+        const unsigned cnt = counters[v];
+        counters[v] = at;
+        at += cnt;
+      }
+    }
+    __syncthreads();
+    for_each_record(n_rec, rvox, [&](unsigned o, unsigned rv) {
+      const unsigned v = rv - vlo;
+      if (v < nv) rec_list[rec_base + atomicAdd(&counters[v], 1u)] = val[o];
+    });
+    __syncthreads();
+    // counters[v] is now one past voxel v's last place
+    for (unsigned i = tid; i < nv; i += kRankBlock) vox_end[rec_base + vlo + i] = counters[i];
+    list_base += total;
+    __syncthreads();
+  }
+  if (tid == 0) vox_cnt[f] = n_vox;
+}
+
+// range of every frame in the global down-sampled arrays (one workgroup)
+// also block_first[f] = first block of kBlock voxels of frame f in k_centroids_lists' grid (entry n_frames: all)
+__global__ void __launch_bounds__(kRankBlock)
+k_frame_vox_scan(FrameInfo* fi, int n_frames, const uint32_t* vox_cnt, uint32_t* block_first, Globals* g)
+{
+  __shared__ unsigned s_w[kRankBlock / kWave + 1];
+  unsigned carry = 0u, bcarry = 0u;
+  for (int base = 0; base < n_frames; base += kRankBlock) {
+    const int f = base + (int)threadIdx.x;
+    const unsigned v = f < n_frames ? vox_cnt[f] : 0u;
+    unsigned total, btotal;
+    const unsigned ex = block_scan_excl_1024(v, s_w, total);
+    const unsigned bex = block_scan_excl_1024((v + kBlock - 1u) / kBlock, s_w, btotal);
+    if (f < n_frames) {
+      fi[f].vox_start = (int)(carry + ex);
+      fi[f].n_vox = (int)v;
+      block_first[f] = bcarry + bex;
+    }
+    carry += total;
+    bcarry += btotal;
+  }
+  if (threadIdx.x == 0) {
+    g->n_vox_total = carry;
+    g->max_vox = bcarry;  // (blocks of the centroid kernel)
+    block_first[n_frames] = bcarry;
+  }
+}
+
+// Centroids (CentroidPoint<PointXYZ>: sequential float sum / n) from the per-voxel record lists: one lane per
+// voxel, one block per kBlock voxels of a frame (k_frame_vox_scan lays the blocks out).  The lists of a block's voxels are one contiguous range
+// of rec_list: copied to LDS, each sorted by its lane (a few entries), then walked exactly as
+// k_centroids_groups walks the sorted records.
+constexpr int kListCap = 6144;  // entries of LDS per block (24 KiB); a block with more sorts and walks in HBM
+
+template <class ListPtr>
+__device__ __forceinline__ void sort_small(ListPtr list, unsigned n)
+{
+  for (unsigned i = 1; i < n; ++i) {
+    const unsigned x = list[i];
+    unsigned j = i;
+    while (j > 0u && list[j - 1u] > x) {
+      list[j] = list[j - 1u];
+      --j;
+    }
+    list[j] = x;
+  }
+}
+
+template <bool FAST, class ListPtr>
+__device__ __forceinline__ void centroid_walk(const DepthSrc& src, const float (&aff)[12], int frame, ListPtr list,
+                                              unsigned cnt, const uint4* rec, float& sx, float& sy, float& sz,
+                                              unsigned& n)
+{
+  constexpr unsigned long long kRowMask = (kChunkCols == 64) ? ~0ull : ((1ull << (kChunkCols & 63)) - 1ull);
+  unsigned r_lo, r_hi, r_rc;
+  {
+    const uint4 t = rec[list[0]];
+    r_lo = t.y;
+    r_hi = t.z;
+    r_rc = t.w;
+  }
+  for (unsigned e = 0; e < cnt;) {
+    // [e, e1): the records of one band of image rows; the second and third stay in registers
+    unsigned e1 = e + 1u;
+    unsigned n_lo = r_lo, n_hi = r_hi, n_rc = r_rc;
+    unsigned b_lo = 0u, b_hi = 0u, b_rc = 0u, c_lo = 0u, c_hi = 0u, c_rc = 0u;
+    while (e1 < cnt) {
+      const uint4 t = rec[list[e1]];
+      n_lo = t.y;
+      n_hi = t.z;
+      n_rc = t.w;
+      if ((n_rc >> 16) != (r_rc >> 16)) break;
+      if (e1 == e + 1u) {
+        b_lo = n_lo;
+        b_hi = n_hi;
+        b_rc = n_rc;
+      } else if (e1 == e + 2u) {
+        c_lo = n_lo;
+        c_hi = n_hi;
+        c_rc = n_rc;
+      }
+      ++e1;
+    }
+    const int n_rows = (e1 == e + 1u) ? 1 : kChunkRows;
+    for (int row = 0; row < n_rows; ++row) {
+      for (unsigned ee = e; ee < e1; ++ee) {
+        unsigned m_lo, m_hi, m_rc;
+        if (ee == e) {
+          m_lo = r_lo; m_hi = r_hi; m_rc = r_rc;
+        } else if (ee == e + 1u) {
+          m_lo = b_lo; m_hi = b_hi; m_rc = b_rc;
+        } else if (ee == e + 2u) {
+          m_lo = c_lo; m_hi = c_hi; m_rc = c_rc;
+        } else {
+          const uint4 t = rec[list[ee]];
+          m_lo = t.y; m_hi = t.z; m_rc = t.w;
+        }
+        unsigned long long m = (unsigned long long)m_lo | ((unsigned long long)m_hi << 32);
+        if (n_rows > 1) m &= kRowMask << (row * kChunkCols);
+        n += (unsigned)__popcll(m);
+        centroid_add_bits<FAST>(src, aff, frame, m_rc, m, sx, sy, sz);
+      }
+    }
+    e = e1;
+    r_lo = n_lo;
+    r_hi = n_hi;
+    r_rc = n_rc;
+  }
+}
+
+template <bool FAST>
+__global__ void __launch_bounds__(kBlock)
+k_centroids_lists(DepthSrc src, const FrameInfo* fi, int n_frames, const uint32_t* block_first, unsigned cpf,
+                  const uint32_t* grp_off, uint32_t* rec_list, const uint32_t* vox_end, const uint4* rec, float4* vox,
+                  int* vox_frame)
+{
+  __shared__ unsigned s_list[kListCap];
+  // frame of this block: the last one whose first block is <= blockIdx.x (frames without voxels own no block)
+  int lo = 0, hi = n_frames;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (block_first[mid] <= blockIdx.x) lo = mid; else hi = mid;
+  }
+  const int frame = lo;
+  const FrameInfo& F = fi[frame];
+  const unsigned n_vox = (unsigned)F.n_vox;
+  const unsigned v0 = (blockIdx.x - block_first[frame]) * kBlock;
+  if (v0 >= n_vox) return;
+  const unsigned rec_base = grp_off[(size_t)frame * cpf];
+  const unsigned v = v0 + threadIdx.x;
+  const bool live = v < n_vox;
+  const unsigned v_last = min(v0 + (unsigned)kBlock, n_vox) - 1u;
+  const unsigned S = v0 > 0u ? vox_end[rec_base + v0 - 1u] : 0u;
+  const unsigned E = vox_end[rec_base + v_last];
+  const unsigned start = live ? (v > 0u ? vox_end[rec_base + v - 1u] : 0u) : 0u;
+  const unsigned cnt = live ? vox_end[rec_base + v] - start : 0u;
+  float aff[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) aff[k] = F.aff[k];
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  unsigned n = 0;
+  if (E - S <= (unsigned)kListCap) {  // (block-uniform)
+    for (unsigned i = threadIdx.x; i < E - S; i += kBlock) s_list[i] = rec_list[rec_base + S + i];
+    __syncthreads();
+    if (live) {
+      unsigned* list = s_list + (start - S);
+      sort_small(list, cnt);
+      centroid_walk<FAST>(src, aff, frame, list, cnt, rec, sx, sy, sz, n);
+    }
+  } else if (live) {
+    uint32_t* list = rec_list + rec_base + start;
+    sort_small(list, cnt);
+    centroid_walk<FAST>(src, aff, frame, list, cnt, rec, sx, sy, sz, n);
+  }
+  if (live) {
+    const float c = (float)n;
+    vox[(unsigned)F.vox_start + v] = make_float4(sx / c, sy / c, sz / c, 0.f);  // every voxel has a record: n > 0
+    vox_frame[(unsigned)F.vox_start + v] = frame;
+  }
+}
+
+}  // namespace hope

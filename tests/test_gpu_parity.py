@@ -233,6 +233,30 @@ def test_group_records_through_the_device_wide_sort(hip_lib, oracle_lib, monkeyp
         assert_frame_equal(o, g, f)
 
 
+def test_group_records_through_the_segmented_sort(hip_lib, oracle_lib, monkeypatch):
+    """Depth batches normally rank their voxels with an LDS bitmap per frame (voxel_rank.hpp: no sort).  The knob
+    sends the group records through the per-frame segmented radix sort + run-length encoding instead: the path
+    of frames whose grid or voxel count does not fit in LDS.  Also: a grid too large for the bitmap (1 cm leaves)
+    takes that path by itself."""
+    depth, t, q = synth_frames(3, first=33)
+    monkeypatch.setenv("HOPE_DEBUG_VOXEL_RANK", "0")
+    g = HopeContext(hip_lib)
+    monkeypatch.delenv("HOPE_DEBUG_VOXEL_RANK")
+    o = HopeContext(oracle_lib)
+    for c in (g, o):
+        c.set_frame_poses(t, q)
+        assert c.segment_depth(depth) == 0
+    for f in range(3):
+        assert_frame_equal(o, g, f)
+    g, o = both(hip_lib, oracle_lib, th_xy=0.01, th_z=0.01)
+    for c in (g, o):
+        c.set_frame_poses(t[:1], q[:1])
+        assert c.segment_depth(depth[:1]) == 0
+    cells = np.prod(np.array(list(o.counts(0).grid), np.int64))
+    assert cells > 160 * 1024 * 8, cells       # more cells than LDS has bits
+    assert_frame_equal(o, g, 0)
+
+
 def test_depth_frames_through_two_passes(hip_lib, oracle_lib, monkeypatch):
     """Depth frames normally take one pass over the batch (k_bbox_records: records with packed cell codes in
     sparse slots, keys made once the bounding box is known).  The knob forces the two-pass path
@@ -518,16 +542,19 @@ def test_invalid_arguments(hip_lib):
 
 
 def test_sub_batches_on_their_own_streams(hip_lib, oracle_lib, monkeypatch):
-    """A batch of many frames runs as up to four frame ranges, each in a child context with its own stream,
-    workspace and host thread (hope_hip.hip: segment_depth_split).  Forced here on 14 frames (ranges of 3-4):
+    """With HOPE_SUB_BATCHES=n a batch of many frames runs as up to n frame ranges, each in a child context with
+    its own stream, workspace and host thread (hope_hip.hip: segment_depth_split; off by default: measured slower
+    than one range on MI355X).  Forced here on 14 frames (ranges of 3-4):
     every stage of every frame equals the oracle's, the per-frame accessors and the objects-on-plane step find
     their frame in the right range, and a later small call leaves the split state behind."""
     from test_upon_plane import winner_contour
     import ctypes
     depth, t, q = synth_frames(14, first=40)
+    monkeypatch.setenv("HOPE_SUB_BATCHES", "4")
     monkeypatch.setenv("HOPE_DEBUG_SUB_MIN", "3")
     g = HopeContext(hip_lib, mode=HOPE_MODE_RT, min_height=0.5, max_height=1.0)
     monkeypatch.delenv("HOPE_DEBUG_SUB_MIN")
+    monkeypatch.delenv("HOPE_SUB_BATCHES")
     o = HopeContext(oracle_lib, mode=HOPE_MODE_RT, min_height=0.5, max_height=1.0)
     for c in (g, o):
         c.set_frame_poses(t, q)
@@ -586,8 +613,7 @@ def test_full_size_batch_properties(hip_lib, oracle_lib):
         assert c.n_raw == valid[f]                      # 0.3 < d/5000 < 8.0  <=>  1500 < d < 40000
         assert 0 < c.n_fit <= c.n_vox <= c.n_raw
         assert c.n_planes <= c.n_clusters <= c.n_segments <= c.n_fit
-    # 36 frames: every 31st, plus both sides of every sub-batch boundary (the batch runs as four ranges of
-    # 256 frames, each on a stream and host thread of its own)
+    # 36 frames: every 31st plus a few more
     sample = sorted(set(list(range(0, F, 31)) + [255, 256, 511, 512, 767, 768, 1023]))
     digests = {f: summary(g, f) for f in sample}
     labels = {f: g.labels(f) for f in sample}

@@ -10,7 +10,7 @@ timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout
 rc=$?
 tail -5 $O/pytest_$tag.log
 [ $rc -ne 0 ] && exit $rc
-for sb in 1 4; do
+for sb in ${SBS:-1}; do
   HOPE_SUB_BATCHES=$sb timeout -k 10 200 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_${tag}_sb$sb.log 2>&1 || { tail -5 $O/bench_${tag}_sb$sb.log; exit 1; }
   python - $O/bench_${tag}_sb$sb.log <<'PY'
 import json, sys
