@@ -118,6 +118,19 @@ def test_multilevel_scene_cloud(hip_lib, oracle_lib):
     assert g.counts(0).n_clusters > 20
 
 
+def test_one_huge_cluster(hip_lib, oracle_lib):
+    """A floor of 8 m x 8 m: one cluster of more than 16384 members (dozens of tiles of k_cluster_verify_b's
+    chains, the union-find tiles of several workgroups)."""
+    rng = np.random.default_rng(5)
+    n = 400000
+    xyz = np.concatenate([rng.uniform(-4, 4, (n, 2)), rng.normal(0.0, 0.002, (n, 1))], 1).astype(np.float32)
+    g, o = both(hip_lib, oracle_lib)
+    for c in (g, o):
+        assert c.segment_cloud(xyz) == 0
+    assert_frame_equal(o, g, 0)
+    assert g.clusters(0)["size"].max() > 16384
+
+
 def test_rt_mode_and_height_window(hip_lib, oracle_lib):
     z = np.load(os.path.join(GOLDEN, "synth_frames_0_2.npz"))
     g, o = both(hip_lib, oracle_lib, mode=HOPE_MODE_RT, min_height=0.6, max_height=0.9)
