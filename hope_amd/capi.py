@@ -139,6 +139,12 @@ class HopeLib:
             f.argtypes = args
             self.fn[name] = f
         # instrumentation entry points exist in the HIP library only
+        # the no-allocation entry point exists in the HIP library only
+        if hasattr(self.dll, prefix + "shard_z_histogram_static"):
+            f = getattr(self.dll, prefix + "shard_z_histogram_static")
+            f.restype = C.c_int
+            f.argtypes = [vp, vp, C.c_size_t, C.c_size_t, i32, vp, vp, i32, i32]
+            self.fn["shard_z_histogram_static"] = f
         self.has_profile = hasattr(self.dll, prefix + "profile_enable")
         if self.has_profile:
             f = getattr(self.dll, prefix + "profile_enable")
@@ -269,6 +275,21 @@ class HopeContext:
         self._check(self.lib.fn["shard_z_histogram"](self._h, ptr, n, stride_bytes, int(apply_filter_transform),
                                                      int(on_device), b.ctypes.data, hist.ctypes.data, n_bins),
                     "shard_z_histogram")
+        return hist
+
+    def shard_z_histogram_static(self, dev_ptr, n, stride_bytes, apply_filter_transform, bbox, n_bins, out_ptr=None):
+        """hope_shard_z_histogram_static: device input, no allocation; the bins go to out_ptr (device) or come
+        back as a numpy array."""
+        b = np.ascontiguousarray(bbox, dtype=np.float32)
+        if out_ptr is not None:
+            self._check(self.lib.fn["shard_z_histogram_static"](self._h, dev_ptr, n, stride_bytes,
+                                                                int(apply_filter_transform), b.ctypes.data, out_ptr,
+                                                                n_bins, 1), "shard_z_histogram_static")
+            return None
+        hist = np.zeros(n_bins, np.int64)
+        self._check(self.lib.fn["shard_z_histogram_static"](self._h, dev_ptr, n, stride_bytes,
+                                                            int(apply_filter_transform), b.ctypes.data,
+                                                            hist.ctypes.data, n_bins, 0), "shard_z_histogram_static")
         return hist
 
     def shard_route(self, ptr, n, stride_bytes, apply_filter_transform, on_device, bbox, layer_owner, n_ranks,

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -23,7 +24,24 @@ using namespace hope;
 
 static_assert(sizeof(ClusterRec) == sizeof(hope_cluster), "ClusterRec must mirror hope_cluster");
 
+// ---- the no-allocation entry point's scratch (hope_shard_z_histogram_static) --------------------------
+// Device memory beyond the caller's input and output that its kernels need: the frame record (pose,
+// bounding box, VoxelGrid grid), the scalars k_frame_grid writes, and the 64-bit bins the workgroups
+// merge their LDS-private votes into.  A file-scope __device__ array: each GPU holds its own copy at its
+// own address, resolved once per device in hope_create (hipGetSymbolAddress) -- in host code the array's
+// name is only a stand-in, never a device address.
+constexpr int kStaticHistBins = kHistLds;  // 8192 z layers (164 m of th_z = 0.02)
+struct StaticScratch {
+  FrameInfo fi;
+  Globals glob;
+  unsigned long long hist[kStaticHistBins];
+};
+static __device__ __align__(256) unsigned char scratch[(sizeof(StaticScratch) + 255) / 256 * 256];
 namespace {
+
+constexpr int kMaxDevices = 64;
+StaticScratch* g_scratch_ptr[kMaxDevices] = {};  // per device; written under g_scratch_mutex
+std::mutex g_scratch_mutex;
 
 struct Pose {
   float t[3];
@@ -145,6 +163,7 @@ struct hope_ctx {
   Arena arena;
   Globals* d_glob = nullptr;
   Globals* h_glob = nullptr;  // pinned
+  StaticScratch* d_scratch = nullptr;  // this device's copy of `scratch` (no-allocation entry point)
   Pose pose;
   std::vector<Pose> frame_poses;
   std::string err;
@@ -1159,6 +1178,22 @@ HOPE_API int hope_create(const hope_config* cfg, hope_ctx** out)
     delete c;
     return HOPE_E_HIP;
   }
+  {
+    // the device's address of the static scratch array, once per device, with that device current
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (cfg->device < kMaxDevices && !g_scratch_ptr[cfg->device]) {
+      void* p = nullptr;
+      const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+      if (e != hipSuccess || !p) {
+        std::fprintf(stderr, "hope_create: hipGetSymbolAddress(scratch) failed: %s\n", hipGetErrorString(e));
+        (void)hipGetLastError();
+        hope_destroy(c);
+        return HOPE_E_HIP;
+      }
+      g_scratch_ptr[cfg->device] = static_cast<StaticScratch*>(p);
+    }
+    c->d_scratch = cfg->device < kMaxDevices ? g_scratch_ptr[cfg->device] : nullptr;
+  }
   const char* knob = std::getenv("HOPE_DEBUG_SMALL_NB_CAP");
   c->normals_cap_small = (knob && knob[0] == '1') ? 1 : 0;
 #ifdef HOPE_ABLATE  // timing experiments (tools/ablate.sh builds its own library): never in the shipped build
@@ -1540,6 +1575,53 @@ HOPE_API int hope_shard_z_histogram(hope_ctx* c, const void* xyz, size_t n, size
   }
   HIPCHK(hipMemcpyAsync(hist, d_hist, sizeof(int64_t) * n_bins, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  return HOPE_OK;
+}
+
+HOPE_API int hope_shard_z_histogram_static(hope_ctx* c, const void* xyz_dev, size_t n, size_t stride, int apply,
+                                           const float bbox[6], int64_t* hist, int n_bins, int hist_on_device)
+{
+  if (!c || !bbox || !hist || n_bins <= 0) return HOPE_E_INVALID;
+  if ((!xyz_dev && n > 0) || stride < 12 || (stride % 4) != 0 || n >= 0xffffffffull) {
+    c->err = "hope_shard_z_histogram_static: bad cloud argument";
+    return HOPE_E_INVALID;
+  }
+  if (n_bins > kStaticHistBins) {
+    c->err = "hope_shard_z_histogram_static: more than 8192 z layers do not fit the static scratch buffer "
+             "(use hope_shard_z_histogram)";
+    return HOPE_E_RANGE;
+  }
+  if (!c->d_scratch) {
+    c->err = "hope_shard_z_histogram_static: no static scratch on this device";
+    return HOPE_E_HIP;
+  }
+  HIPCHK(hipSetDevice(c->cfg.device));
+  StaticScratch* sp = c->d_scratch;  // (the device address: never the array's name)
+  hipStream_t s = c->stream;
+  CloudSrc src;
+  src.base = static_cast<const char*>(xyz_dev);
+  src.stride = stride;
+  src.n = (unsigned)n;
+  src.apply = apply ? 1 : 0;
+  src.min_d = c->cfg.min_depth;
+  src.max_d = c->cfg.max_depth;
+  // every call on this GPU shares the array, which keeps the last call's contents: the frame record is
+  // written whole, the scalars and the bins in use are cleared
+  StaticFrame sf;
+  make_affine(c->pose, sf.aff);
+  for (int d = 0; d < 6; ++d) sf.bbox[d] = bbox[d];
+  hipLaunchKernelGGL(k_static_frame, dim3(1), dim3(1), 0, s, &sp->fi, sf);
+  HIPCHK(hipMemsetAsync(&sp->glob, 0, sizeof(Globals), s));
+  HIPCHK(hipMemsetAsync(sp->hist, 0, sizeof(unsigned long long) * (size_t)n_bins, s));
+  hipLaunchKernelGGL(k_frame_grid, dim3(1), dim3(1024), 0, s, &sp->fi, 1, c->inv_xy, c->inv_z, 0u, &sp->glob);
+  if (n > 0) {
+    const unsigned bx = std::max(1u, std::min<unsigned>(nblk(n, kBlock * 16), 2048u));
+    hipLaunchKernelGGL((k_z_histogram<CloudSrc>), dim3(bx), dim3(kBlock), 0, s, src, &sp->fi, c->inv_z, n_bins, sp->hist);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(hist, sp->hist, sizeof(int64_t) * (size_t)n_bins,
+                        hist_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
   return HOPE_OK;
 }
 

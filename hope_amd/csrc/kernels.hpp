@@ -2152,6 +2152,25 @@ __global__ void k_force_bbox(FrameInfo* fi, float mnx, float mny, float mnz, flo
   fi[0].bb_max[2] = f2ord(mxz);
 }
 
+// the frame record of a call that brings pose and bounding box as kernel arguments (no host-to-device copy):
+// all of it is written, so nothing of an earlier call survives in it
+struct StaticFrame {
+  float aff[12];
+  float bbox[6];
+};
+__global__ void k_static_frame(FrameInfo* fi, StaticFrame sf)
+{
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  FrameInfo F = {};
+  for (int k = 0; k < 12; ++k) F.aff[k] = sf.aff[k];
+  for (int d = 0; d < 3; ++d) {
+    F.bb_min[d] = f2ord(sf.bbox[d]);
+    F.bb_max[d] = f2ord(sf.bbox[3 + d]);
+  }
+  F.n_raw = 1;  // (k_frame_grid only builds a grid for a frame with points)
+  *fi = F;
+}
+
 // z-layer histogram of the surviving points: layer = VoxelGrid's k index.  Votes go to LDS-private
 // bins of the workgroup (one ds_add per point; layers of a horizontal surface repeat within a
 // wave, which the LDS atomic unit serialises cheaply) and are merged into the 64-bit global bins
