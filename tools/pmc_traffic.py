@@ -19,7 +19,7 @@ from collections import defaultdict
 STAGE_OF = [  # kernel name fragment -> bench.py stage
     ("k_bbox", "k_bbox"), ("k_frame_grid", "k_frame_grid"), ("k_group_records", "k_voxel_keys"),
     ("k_group_keys", "k_voxel_keys"), ("k_fit_sorted", "fit_column_index"), ("k_fit_col_table", "fit_column_index"),
-    ("k_voxel_keys", "k_voxel_keys"), ("k_centroids", "k_centroids"), ("k_column_keys", "k_column_keys"),
+    ("k_voxel_rank", "k_voxel_rank"), ("k_frame_vox_scan", "k_voxel_rank"), ("k_voxel_keys", "k_voxel_keys"), ("k_centroids", "k_centroids"), ("k_column_keys", "k_column_keys"),
     ("k_column_table", "k_column_table+gather"), ("k_gather_sorted", "k_column_table+gather"),
     ("k_normals_tile", "k_normals"), ("k_fit_", "fit_gate+compact"), ("k_frame_fit", "fit_gate+compact"),
     ("k_knn_todo", "k_knn_todo"), ("k_knn", "k_knn"), ("k_coarse", "k_knn_todo"), ("k_gather_coarse", "k_knn_todo"),

@@ -14,7 +14,10 @@ timeout -s KILL 150 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format cs
 timeout -s KILL 150 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_$tag -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_write_$tag.log 2>&1 || { tail -5 $O/pmc_write_$tag.log; exit 1; }
 echo "pmc done"
 cd $R
-timeout -k 10 200 python tools/bench_cloud.py --kind multilevel --points 100000000 > $O/cloud100M_$tag.json 2> $O/cloud100M_$tag.err || { tail -5 $O/cloud100M_$tag.err; exit 1; }
+timeout -k 10 300 python bench.py --workload cloud > $O/cloud100M_$tag.json 2> $O/cloud100M_$tag.err || { tail -5 $O/cloud100M_$tag.err; exit 1; }
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cloud_$tag -- python3 $R/bench.py --workload cloud --steps 3 --warmup 1 --no-cpu-baseline > $O/prof_cloud_$tag.log 2>&1 || { tail -5 $O/prof_cloud_$tag.log; exit 1; }
+cd $R
 timeout -k 10 200 python tools/bench_cloud.py --kind loft --points 5000000 > $O/cloud5M_$tag.json 2> $O/cloud5M_$tag.err || { tail -5 $O/cloud5M_$tag.err; exit 1; }
 timeout -k 10 200 python tools/bench_rt.py > $O/rt_$tag.json 2> $O/rt_$tag.err || { tail -5 $O/rt_$tag.err; exit 1; }
 echo "all done"
