@@ -36,6 +36,18 @@
 #include "../include/hope_detmath.h"
 #include "../include/hope_gpu.h"
 
+// Order study (tools/order_study.py): each macro flips one of the orders the oracle fixes where PCL / FLANN /
+// Eigen leave them unspecified ("ORDER FIXED" below) to another order those libraries could legally produce.
+#ifndef HOPE_ORACLE_VOXEL_ORDER
+#define HOPE_ORACLE_VOXEL_ORDER 0
+#endif
+#ifndef HOPE_ORACLE_TIE_ORDER
+#define HOPE_ORACLE_TIE_ORDER 0
+#endif
+#ifndef HOPE_ORACLE_COV_ORDER
+#define HOPE_ORACLE_COV_ORDER 0
+#endif
+
 namespace {
 
 #ifdef HOPE_ORACLE_LIBM
@@ -222,8 +234,19 @@ void voxel_grid(const hope_ctx* c, Frame& f)
     const int idx = ijk[0] * mul[0] + ijk[1] * mul[1] + ijk[2] * mul[2];
     iv.emplace_back((unsigned)idx, (unsigned)i);
   }
+#if HOPE_ORACLE_VOXEL_ORDER == 1
+  // order study (tools/order_study.py): PCL's own call, std::sort with operator< on idx only -- unstable, so the
+  // points of a voxel are summed in whatever order libstdc++'s introsort leaves them
+  std::sort(iv.begin(), iv.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+#elif HOPE_ORACLE_VOXEL_ORDER == 2
+  // order study: descending point index inside a voxel
+  std::stable_sort(iv.begin(), iv.end(), [](const auto& a, const auto& b) {
+    return a.first < b.first || (a.first == b.first && a.second > b.second);
+  });
+#else
   std::stable_sort(iv.begin(), iv.end(),
                    [](const auto& a, const auto& b) { return a.first < b.first; });
+#endif
   size_t i = 0;
   while (i < iv.size()) {
     size_t j = i;
@@ -320,7 +343,17 @@ struct KdTree {
     return (dx * dx + dy * dy) + dz * dz;
   }
 
+#if HOPE_ORACLE_TIE_ORDER == 1
+  struct DI {  // order study: equidistant neighbours in DESCENDING index
+    float first;
+    int second;
+    DI() : first(0.f), second(0) {}
+    DI(float d, int i) : first(d), second(i) {}
+    bool operator<(const DI& o) const { return first < o.first || (first == o.first && second > o.second); }
+  };
+#else
   typedef std::pair<float, int> DI;  // lexicographic (dist2, index)
+#endif
 
   void radius_rec(int id, float qx, float qy, float qz, float r2, std::vector<DI>& out) const
   {
@@ -689,7 +722,12 @@ bool normal_analysis(const Frame& f, const std::vector<int>& idx, float th_angle
   // mean_2d is recomputed from data_2d: same sums, same order
   const float mean2_0 = m0, mean2_1 = m1;
   float cxx = 0.f, cxy = 0.f, cyy = 0.f;
-  for (size_t i = 0; i < sz; ++i) {
+  for (size_t k = 0; k < sz; ++k) {
+#if HOPE_ORACLE_COV_ORDER == 1
+    const size_t i = sz - 1 - k;  // order study: the covariance sums in reverse point order
+#else
+    const size_t i = k;
+#endif
     const float tx = f.fnx[idx[i]] - mean2_0;
     const float ty = f.fny[idx[i]] - mean2_1;
     cxx += tx * tx;
