@@ -646,6 +646,66 @@ def test_full_size_batch_properties(hip_lib, oracle_lib):
         assert summary(o, 0) == digests[f]
 
 
+def _cloud_properties(g, n_in):
+    c = g.counts(0)
+    assert c.n_in == n_in and 0 < c.n_fit <= c.n_vox <= c.n_raw <= n_in
+    assert c.n_planes <= c.n_clusters <= c.n_segments <= c.n_fit
+    labels, cl = g.labels(0), g.clusters(0)
+    assert len(cl) == c.n_clusters and int(cl["pass"].sum()) == c.n_planes
+    assert np.array_equal(np.bincount(labels[labels >= 0], minlength=len(cl)), cl["size"])
+    assert (cl["size"] >= 3).all() and np.all(np.diff(cl["seed_rank"]) > 0)
+    fit = g.fit_indices(0)
+    assert np.all(np.diff(fit) > 0) and fit[-1] < c.n_vox
+    vox = g.downsampled(0)
+    key = np.floor(vox * np.float32([20, 20, 50])).astype(np.int64) - np.array(list(c.min_b), np.int64)
+    lin = key[:, 0] + key[:, 1] * c.grid[0] + key[:, 2] * c.grid[0] * c.grid[1]
+    assert np.all(np.diff(lin) > 0)                      # VoxelGrid order: one centroid per cell, ascending index
+    return summary(g, 0)
+
+
+def test_full_size_loft_cloud(hip_lib, oracle_lib):
+    """BASELINE.json configs[2] stand-in at full size (5 million points; loft.ply itself is not in the image):
+    size-independent properties, idempotence, and exact parity with the oracle on the whole cloud."""
+    from hope_amd import synth
+    xyz = synth.make_loft_cloud(5_000_000)
+    g, o = both(hip_lib, oracle_lib)
+    assert g.segment_cloud(xyz) == 0
+    d1 = _cloud_properties(g, xyz.shape[0])
+    assert g.segment_cloud(xyz) == 0
+    assert summary(g, 0) == d1
+    assert o.segment_cloud(xyz) == 0
+    assert_frame_equal(o, g, 0)
+
+
+def test_full_size_multilevel_scene(hip_lib, oracle_lib):
+    """BASELINE.json configs[3] at full size: the 10^8-point multi-level scene, generated on the device.  The
+    oracle cannot run it in seconds: size-independent properties and idempotence on the whole scene, exact
+    parity on a 6 m x 6 m crop of it (same density: ~5 million points, tens of points per voxel)."""
+    import torch
+    from hope_amd import synth
+    n = 100_000_000
+    parts = [synth.make_multilevel_cloud(10_000_000, first_index=i0, device="cuda") for i0 in range(0, n, 10_000_000)]
+    xyz = torch.cat(parts)
+    del parts
+    torch.cuda.synchronize()
+    g, o = both(hip_lib, oracle_lib)
+    assert g.segment_cloud_device(xyz.data_ptr(), n, 12) == 0
+    d1 = _cloud_properties(g, n)
+    c = g.counts(0)
+    assert c.n_raw == n and all(590 <= v <= 610 for v in list(c.grid)[:2])   # 30 m x 30 m at 0.05 m
+    assert g.clusters(0)["size"].max() > 300_000                               # the floor: one huge cluster
+    assert g.segment_cloud_device(xyz.data_ptr(), n, 12) == 0
+    assert summary(g, 0) == d1
+    crop = xyz[(xyz[:, 0] > 10.0) & (xyz[:, 0] < 16.0) & (xyz[:, 1] > 8.0) & (xyz[:, 1] < 14.0)].contiguous()
+    torch.cuda.synchronize()
+    del xyz
+    assert 3_000_000 < crop.shape[0] < 8_000_000
+    assert g.segment_cloud_device(crop.data_ptr(), crop.shape[0], 12) == 0
+    assert o.segment_cloud(crop.cpu().numpy()) == 0
+    assert_frame_equal(o, g, 0)
+    assert g.counts(0).n_planes > 0
+
+
 @pytest.mark.gpu
 def test_hope_node_and_rt_adapter_on_the_device(oracle_lib, tum_example, tmp_path):
     """The C++ host layer linked on libhope_hip.so: `hope_node` (single pair, list mode) and the PlaneSegmentRT
@@ -670,6 +730,15 @@ def test_hope_node_and_rt_adapter_on_the_device(oracle_lib, tum_example, tmp_pat
     for i, rec in enumerate(recs):
         k, planes = expected_planes(oracle_lib, g["depth"][i], g["t"][2], g["q"][i])
         check_record(rec, k, planes)
+    # F4 plane-ID tracking across the frames of the list (plane_segment.cpp:496-517, utilities.cpp:1063-1159): the
+    # device build hands out the ids the oracle build of the same node hands out; first detection = 0..n-1
+    node_oracle = os.path.join(ROOT, "tests", "_build", "hope_node_oracle")
+    r2, recs2 = run_node(node_oracle, [d], tmp_path, hull=False)
+    assert r2.returncode == 0 and len(recs2) == 3, r2.stderr
+    assert [p["id"] for p in recs[0]["planes"]] == list(range(len(recs[0]["planes"])))
+    for a, b in zip(recs, recs2):
+        assert [p["id"] for p in a["planes"]] == [p["id"] for p in b["planes"]]
+        assert len(set(p["id"] for p in a["planes"])) == len(a["planes"])
     # RT adapter: the same driver on the oracle build and on the device build prints the same line
     z = depth.astype(np.float32) / np.float32(5000.0)
     cols = (np.arange(640, dtype=np.float32) - np.float32(318.6))[None, :]

@@ -197,3 +197,24 @@ def test_voxelgrid_leaf_too_small_passes_the_input_through(oracle_lib):
     near = np.concatenate([a, a + [1.0, 0.0, 0.3]]).astype(np.float32)
     assert c.segment_cloud(near) == 0
     assert c.counts(0).vox_passthrough == 0 and c.counts(0).n_vox < 300
+
+
+def test_fixed_orders_move_plane_heights_by_less_than_a_millimetre():
+    """tools/order_study.py: flipping any one of the orders the oracle fixes (voxel sums, neighbour ties,
+    covariance sums) to another legal order keeps the cluster count, and moves no plane height by 1 mm."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "variants"])
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import order_study
+    z = np.load(os.path.join(GOLDEN, "synth_frames_0_2.npz"))
+    g = np.load(os.path.join(GOLDEN, "tum_example_depth.npz"))
+    inputs = [(g["depth"], g["t"], g["q"])] + [(z["depth"][i], z["t"][i], z["q"][i]) for i in range(3)]
+    from hope_amd.capi import HopeLib
+    base = order_study.run(HopeLib(os.path.join(order_study.BUILD, "libhope_oracle.so"), "hope_oracle_"), inputs)
+    for tag, _ in order_study.VARIANTS:
+        var = order_study.run(HopeLib(os.path.join(order_study.BUILD, f"libhope_oracle_{tag}.so"), "hope_oracle_"), inputs)
+        r = order_study.compare(base, var)
+        assert r["cl_diff"] == 0 and r["unmatched"] == 0 and r["dz_mm"] < 1.0 and r["max_m"] < 1e-5, (tag, r)
+        assert abs(r["planes_b"] - r["planes_v"]) <= 1, (tag, r)
