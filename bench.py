@@ -257,6 +257,8 @@ def main():
     if world > 1 and args.workload == "frames":
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)   # (sharded cloud: every rank already holds the whole result)
     tot_raw = float(tot[0].item())
+    if args.workload == "cloud" and world > 1 and rank == 0 and info.get("result") is not None:
+        tot[3] = float(info["result"]["n_planes"])   # (A9..A12 per z band: rank 0 holds the merged records)
 
     if rank == 0:
         stages, roofline = stage_report(ctx.profile(), args.steps,

@@ -58,16 +58,72 @@ def records_equal(a, b):
 
 # ---- one cloud across several ranks --------------------------------------------------------------
 def band_partition(hist, world):
-    """Owner rank of every z layer: contiguous bands holding about equal numbers of points
-    (hist: all-reduced survivors per layer).  Deterministic, so every rank derives the same map."""
+    """Owner rank of every z layer: contiguous bands holding about equal numbers of points (hist: all-reduced
+    survivors per layer).  Deterministic, so every rank derives the same map.
+
+    ZGrowing only links neighbours with |dz| < th_z (z_growing.cpp:335-364) and a layer is th_z tall, so an
+    EMPTY layer separates clusters exactly: bands cut there are independent extraction problems for A9..A12.
+    A cut is legal when the layer on either side of it is empty; among the legal cuts the one nearest the
+    equal-population target is taken (several ranks may get the same cut: a rank then owns nothing).  Without
+    any empty layer the cuts fall at equal population and the caller has to check for edges across them."""
     hist = np.asarray(hist, dtype=np.int64)
     total = int(hist.sum())
-    owner = np.zeros(hist.shape[0], np.int32)
-    if total == 0 or world == 1:
+    n = hist.shape[0]
+    owner = np.zeros(n, np.int32)
+    if total == 0 or world == 1 or n == 0:
         return owner
-    before = np.cumsum(hist) - hist          # points in the layers below
+    upto = np.cumsum(hist)                    # points in layers 0..k
+    # cut k = between layers k and k + 1
+    legal = [k for k in range(n - 1) if hist[k] == 0 or hist[k + 1] == 0]
+    if legal:
+        cuts, prev = [], -1
+        lg = np.asarray(legal)
+        for r in range(1, world):
+            target = total * r // world
+            cand = lg[lg >= prev]
+            if cand.size == 0:
+                cand = lg[-1:]
+            k = int(cand[np.argmin(np.abs(upto[cand] - target))])
+            k = max(k, prev)
+            cuts.append(k)
+            prev = k
+        for k in cuts:
+            owner[k + 1:] += 1
+        return owner
+    before = upto - hist                      # points in the layers below
     owner[:] = np.minimum((before * world) // total, world - 1).astype(np.int32)
     return owner
+
+
+def merge_band_results(parts, n_fit):
+    """parts: per rank (lo, hi, clusters of the own band [CLUSTER_DTYPE, with the GLOBAL seed rank], labels of
+    the own fit points [lo, hi) as indices into those clusters, segments among the own points), in rank order.
+    Returns the whole cloud's result: clusters in the reference's order (ascending seed rank,
+    z_growing.cpp:229-282), labels of all fit points as indices into that list."""
+    from hope_amd.capi import CLUSTER_DTYPE
+    recs = np.concatenate([np.asarray(p[2], dtype=CLUSTER_DTYPE) for p in parts]) if parts else np.zeros(0, CLUSTER_DTYPE)
+    src = np.concatenate([np.full(len(p[2]), r, np.int64) for r, p in enumerate(parts)]) if parts else np.zeros(0, np.int64)
+    order = np.argsort(recs["seed_rank"], kind="stable")
+    assert len(set(recs["seed_rank"].tolist())) == len(recs)      # a seed belongs to exactly one band
+    new_id = np.empty(len(recs), np.int64)
+    new_id[order] = np.arange(len(recs))
+    first = np.cumsum([0] + [len(p[2]) for p in parts])
+    labels = np.full(n_fit, -1, np.int32)
+    for r, (lo, hi, cl, lab, _) in enumerate(parts):
+        lab = np.asarray(lab, np.int64)
+        out = np.where(lab >= 0, new_id[first[r] + np.maximum(lab, 0)] if len(cl) else -1, -1)
+        labels[lo:hi] = out.astype(np.int32)
+    clusters = recs[order]
+    return {"clusters": clusters, "labels": labels, "n_segments": int(sum(p[4] for p in parts)),
+            "n_clusters": int(len(clusters)), "n_planes": int((clusters["pass"] == 1).sum())}
+
+
+def whole_result(ctx):
+    """The same dictionary from a ctx that holds the whole cloud's result (replicated path, one rank)."""
+    c = ctx.counts(0)
+    cl = ctx.clusters(0)
+    return {"clusters": cl, "labels": ctx.labels(0), "n_segments": int(c.n_segments), "n_clusters": int(c.n_clusters),
+            "n_planes": int((cl["pass"] == 1).sum()) if len(cl) else 0}
 
 
 def _ptr(t):
@@ -95,13 +151,18 @@ def _all_gather_rows(mine, sizes, dist):
     return torch.cat([p[:s] for p, s in zip(parts, sizes)]).contiguous()
 
 
-def segment_cloud_sharded(ctx, xyz_local, dist, apply_filter_transform=False):
+def segment_cloud_sharded(ctx, xyz_local, dist, apply_filter_transform=False, allow_bands=True):
     """xyz_local: this rank's contiguous share of the cloud, float32 torch tensor [n, 3] (CPU with
     gloo, cuda with nccl = RCCL).  Ranks hold the points in rank order (rank 0 the lowest indices).
-    Afterwards `ctx` of EVERY rank holds the result of the whole cloud (A6 and A8 shared by z band,
-    the rest replicated on the gathered down-sampled cloud), exactly as if one process had called
-    segment_cloud on it.
-    Returns a dict of the exchanged sizes."""
+    A6 and A8 are shared by z band.  A9..A12 run per z band too when the bands are independent (cuts at empty
+    z layers; checked on the k-NN rows): every rank then grows and verifies the clusters of its own band only and
+    rank 0 merges the records by seed rank -- info["path"] == "z-bands", info["result"] on rank 0 (None elsewhere).
+    Otherwise (edges cross the cuts) the k-NN rows are all-gathered and A9..A12 run on every rank on the whole fit
+    cloud -- info["path"] == "replicated", info["result"] on every rank, and `ctx` holds the whole result exactly
+    as if one process had called segment_cloud.  info["result"] = merge_band_results' dictionary (clusters in the
+    reference's order, labels of all fit points, n_segments, n_clusters, n_planes); A1..A8 accessors of `ctx` are
+    those of the whole cloud on both paths.
+    Returns a dict of the exchanged sizes, the path taken and the result."""
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
     xyz_local = xyz_local.contiguous()
@@ -120,7 +181,8 @@ def segment_cloud_sharded(ctx, xyz_local, dist, apply_filter_transform=False):
     gbbox = np.concatenate([-mmh[:3], mmh[3:]]).astype(np.float32)
     if n_raw_total == 0:
         ctx.segment_cloud(np.zeros((0, 3), np.float32))
-        return {"n_raw_total": 0, "n_vox": 0, "sent": [0] * world, "received": [0] * world}
+        return {"n_raw_total": 0, "n_vox": 0, "sent": [0] * world, "received": [0] * world, "path": "empty",
+                "result": whole_result(ctx)}
     _, div_b, st = ctx.grid_from_bbox(gbbox)
     n_bins = int(div_b[2])
     # 2. z-layer histogram -> bands
@@ -160,10 +222,12 @@ def segment_cloud_sharded(ctx, xyz_local, dist, apply_filter_transform=False):
     _sync(vox_all)
     if n_vox == 0:
         ctx.segment_cloud(np.zeros((0, 3), np.float32))
-        return {"n_raw_total": n_raw_total, "n_vox": 0, "sent": send_l, "received": recv_l, "bands": owner}
+        return {"n_raw_total": n_raw_total, "n_vox": 0, "sent": send_l, "received": recv_l, "bands": owner,
+                "path": "empty", "result": whole_result(ctx)}
     if world == 1:
         ctx.segment_downsampled(vox_all.data_ptr(), n_vox, 12, vox_all.is_cuda, gbbox, n_raw_total)
-        return {"n_raw_total": n_raw_total, "n_vox": n_vox, "sent": send_l, "received": recv_l, "bands": owner}
+        return {"n_raw_total": n_raw_total, "n_vox": n_vox, "sent": send_l, "received": recv_l, "bands": owner,
+                "path": "one rank", "result": whole_result(ctx)}
     first, count = sum(sizes_l[:rank]), sizes_l[rank]
     args = (vox_all.data_ptr(), n_vox, 12, vox_all.is_cuda, gbbox, n_raw_total, first, count)
     ctx.segment_downsampled_staged(*args, stop_after=1)
@@ -178,13 +242,58 @@ def segment_cloud_sharded(ctx, xyz_local, dist, apply_filter_transform=False):
     fit_sizes[rank] = hi - lo
     dist.all_reduce(fit_sizes, op=dist.ReduceOp.SUM)
     fit_sizes_l = [int(v) for v in fit_sizes.cpu().tolist()]
-    if sum(fit_sizes_l) == 0:
-        knn_all = torch.zeros((1, ctx.cfg.knn), dtype=torch.int32, device=dev)
-    else:
-        own_k = torch.empty((hi - lo, ctx.cfg.knn), dtype=torch.int32, device=dev)
+    n_fit = sum(fit_sizes_l)
+    base = {"n_raw_total": n_raw_total, "n_vox": n_vox, "n_fit": n_fit, "sent": send_l, "received": recv_l,
+            "bands": owner, "own_vox": sizes_l, "own_fit": fit_sizes_l}
+    K = ctx.cfg.knn
+    own_k = torch.empty((hi - lo, K), dtype=torch.int32, device=dev)
+    if hi > lo:
         ctx.knn_rows(lo, hi - lo, out_ptr=own_k.data_ptr(), out_on_device=own_k.is_cuda)
+    # 6. A9..A12 by z band when the bands are independent: no valid edge (|dz| < th_z, validatePoint
+    #    z_growing.cpp:335-364) leaves a band.  True by construction when the cuts sit at empty layers; checked
+    #    on the k-NN rows themselves (every rank its own rows: an edge into a band is an edge out of another).
+    crossing = torch.zeros(1, dtype=torch.int32, device=dev)
+    if hi > lo and allow_bands:
+        fit_t = torch.from_numpy(np.ascontiguousarray(fit_idx, dtype=np.int64)).to(dev)
+        z = vox_all[fit_t, 2]
+        nb = own_k.to(torch.int64)
+        valid = nb >= 0
+        foreign = valid & ((nb < lo) | (nb >= hi))
+        dz = (z[lo:hi, None] - z[nb.clamp(min=0)]).abs()
+        th_z = torch.tensor(ctx.cfg.th_z, dtype=torch.float32, device=dev)
+        crossing[0] = int(bool((foreign & (dz < th_z)).any().item()))
+    if not allow_bands:
+        crossing[0] = 1
+    dist.all_reduce(crossing, op=dist.ReduceOp.MAX)
+    if int(crossing.item()) == 0:
+        # every band is closed under the neighbour relation: regions grow, and clusters are verified, inside the
+        # own band only; the points of other bands come as rows without neighbours (singletons, dropped by the
+        # size filter).  Seed ranks are those of the whole fit cloud, so rank 0 merges by seed rank.
+        knn_part = torch.full((max(n_fit, 1), K), -1, dtype=torch.int32, device=dev)
+        knn_part[lo:hi] = own_k
+        _sync(knn_part)
+        ctx.segment_downsampled_staged(*args, normals_ptr=normals_all.data_ptr(), knn_ptr=knn_part.data_ptr(), stop_after=0)
+        c = ctx.counts(0)
+        cl = ctx.clusters(0).copy()
+        lab = ctx.labels(0)[lo:hi].copy()
+        seg_own = int(c.n_segments) - (n_fit - (hi - lo)) if ctx.cfg.min_cluster > 1 else int(c.n_segments)
+        mine_part = (lo, hi, cl, lab, seg_own)
+        if rank == 0:
+            parts = [None] * world
+            dist.gather_object(mine_part, parts, dst=0)
+            merged = merge_band_results(parts, n_fit)
+        else:
+            dist.gather_object(mine_part, None, dst=0)
+            merged = None
+        base.update({"path": "z-bands", "result": merged})
+        return base
+    # fallback: edges cross the band cuts (no empty layer to cut at): all-gather the k-NN rows and run A9..A12
+    # on the whole fit cloud on every rank
+    if n_fit == 0:
+        knn_all = torch.zeros((1, K), dtype=torch.int32, device=dev)
+    else:
         knn_all = _all_gather_rows(own_k, fit_sizes_l, dist)
     _sync(knn_all)
     ctx.segment_downsampled_staged(*args, normals_ptr=normals_all.data_ptr(), knn_ptr=knn_all.data_ptr(), stop_after=0)
-    return {"n_raw_total": n_raw_total, "n_vox": n_vox, "n_fit": sum(fit_sizes_l), "sent": send_l, "received": recv_l,
-            "bands": owner, "own_vox": sizes_l, "own_fit": fit_sizes_l}
+    base.update({"path": "replicated", "result": whole_result(ctx)})
+    return base

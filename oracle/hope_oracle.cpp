@@ -102,6 +102,10 @@ struct hope_ctx {
   float th_theta, th_angle, th_norm;
   const float* forced_bbox = nullptr;  // staged (multi-rank) calls: the all-reduced bounding box
   int stop_after_voxel = 0, input_is_downsampled = 0;
+  // staged call, z-band form: k-NN rows given from outside; a row of -1 is a point of another band (no
+  // neighbours here), every other row must equal the oracle's own (knn_mismatch otherwise)
+  const int32_t* band_knn = nullptr;
+  mutable long long knn_mismatch = -1;
   Pose pose;
   std::vector<Pose> frame_poses;
   std::vector<Frame> frames;
@@ -603,6 +607,17 @@ void z_growing(const hope_ctx* c, Frame& f, const KdTree* tree)
       best.resize(k);
     }
     for (int j = 0; j < (int)best.size(); ++j) f.knn[(size_t)i * K + j] = best[j].second;
+  }
+  if (c->band_knn) {
+    for (int i = 0; i < n; ++i) {
+      const int32_t* row = c->band_knn + (size_t)i * K;
+      bool foreign = true;
+      for (int j = 0; j < K; ++j) foreign &= row[j] == -1;
+      for (int j = 0; j < K; ++j) {
+        if (foreign) f.knn[(size_t)i * K + j] = -1;
+        else if (f.knn[(size_t)i * K + j] != row[j] && c->knn_mismatch < 0) c->knn_mismatch = (long long)i * K + j;
+      }
+    }
   }
 
   std::vector<int> point_labels(n, -1);
@@ -1207,7 +1222,12 @@ ORACLE_API int hope_oracle_segment_downsampled_staged(hope_ctx* ctx, const void*
   if (!ctx || !bbox || own_first < 0 || own_count < 0 || (size_t)(own_first + own_count) > n_vox || stop_after < 0 ||
       stop_after > 2)
     return HOPE_E_INVALID;
+  // (k-NN rows that are all -1 mark the points of other z bands: the regions then grow inside the own band
+  // only; every other row is checked against the oracle's own)
+  ctx->band_knn = knn_all;
+  ctx->knn_mismatch = -1;
   const int st = oracle_cloud_staged(ctx, vox, n_vox, stride, bbox, 0, 1, n_raw_total);
+  ctx->band_knn = nullptr;
   if (st < 0 || ctx->frames.empty()) return st;
   const Frame& f = ctx->frames[0];
   if (normals_all) {
@@ -1219,13 +1239,9 @@ ORACLE_API int hope_oracle_segment_downsampled_staged(hope_ctx* ctx, const void*
       }
     }
   }
-  if (knn_all) {
-    for (size_t i = 0; i < f.knn.size(); ++i) {
-      if (f.knn[i] != knn_all[i]) {
-        ctx->err = "staged call: gathered k-NN rows differ from the oracle's at entry " + std::to_string(i);
-        return HOPE_E_INVALID;
-      }
-    }
+  if (knn_all && ctx->knn_mismatch >= 0) {
+    ctx->err = "staged call: gathered k-NN rows differ from the oracle's at entry " + std::to_string(ctx->knn_mismatch);
+    return HOPE_E_INVALID;
   }
   return st;
 }

@@ -69,7 +69,28 @@ def _cloud(n=60000):
     return xyz
 
 
-def _cloud_worker(rank, world, port, q, apply):
+def _layer_cloud():
+    """Horizontal patches at four heights with nothing between them: empty z layers to cut the bands at."""
+    rng = np.random.default_rng(17)
+    pts = []
+    for k, (zc, n) in enumerate(((0.0, 30000), (0.71, 9000), (1.52, 12000), (2.33, 7000))):
+        ox = -2.0 + 0.3 * k
+        xy = rng.uniform(0.0, 3.0 - 0.5 * k, (n, 2)).astype(np.float32) + np.float32([ox, -1.0])
+        pts.append(np.concatenate([xy, (zc + rng.normal(0.0, 0.002, n)).astype(np.float32)[:, None]], 1))
+    xyz = np.concatenate(pts).astype(np.float32)
+    return xyz[rng.permutation(len(xyz))]
+
+
+def _ramp_cloud():
+    """A gentle ramp (z = 0.2 x): every z layer is populated and neighbours link across all of them."""
+    rng = np.random.default_rng(23)
+    n = 60000
+    xy = rng.uniform(0.0, 3.0, (n, 2)).astype(np.float32)
+    z = (0.2 * xy[:, 0] + rng.normal(0.0, 0.001, n)).astype(np.float32)
+    return np.concatenate([xy, z[:, None]], 1).astype(np.float32)
+
+
+def _cloud_worker(rank, world, port, q, apply, layered=False, allow_bands=True):
     import torch
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -79,17 +100,79 @@ def _cloud_worker(rank, world, port, q, apply):
     from hope_amd.sharding import frame_partition, segment_cloud_sharded
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from parity import summary
-    xyz = _cloud()
+    xyz = _layer_cloud() if layered is True else (_ramp_cloud() if layered == "ramp" else _cloud())
     if apply:
         xyz = xyz * np.float32(0.25) + np.array([0, 0, 0.2], np.float32)
     lo, hi = frame_partition(xyz.shape[0], world, rank)
     ctx = HopeContext(HopeLib(ORACLE_LIB, "hope_oracle_"))
     if apply:
         ctx.set_pose(np.array([0.1, -0.2, 0.3], np.float32), np.array([0.02, -0.01, 0.38, 0.92], np.float32))
-    info = segment_cloud_sharded(ctx, torch.from_numpy(xyz[lo:hi].copy()), dist, apply_filter_transform=apply)
+    info = segment_cloud_sharded(ctx, torch.from_numpy(xyz[lo:hi].copy()), dist, apply_filter_transform=apply,
+                                 allow_bands=allow_bands)
     dist.barrier()
-    q.put((rank, summary(ctx, 0), info["sent"], info["received"]))
+    res = info["result"]
+    if res is not None:
+        res = {"clusters": np.asarray(res["clusters"]).tobytes(), "labels": np.asarray(res["labels"]).tobytes(),
+               "n_segments": res["n_segments"], "n_clusters": res["n_clusters"], "n_planes": res["n_planes"]}
+    q.put((rank, summary(ctx, 0), info["sent"], info["received"], info["path"], res,
+           [int(v) for v in info.get("own_fit", [])]))
     dist.destroy_process_group()
+
+
+def _run_ranks(world, port, **kw):
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    procs = [mpctx.Process(target=_cloud_worker, args=(r, world, port, q, kw.get("apply", False), kw.get("layered", False),
+                                                       kw.get("allow_bands", True))) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(got, key=lambda g: g[0])
+
+
+def _single_result(oracle_lib, xyz):
+    from hope_amd.capi import HopeContext
+    ctx = HopeContext(oracle_lib)
+    ctx.segment_cloud(xyz)
+    c = ctx.counts(0)
+    cl = ctx.clusters(0)
+    return {"clusters": cl.tobytes(), "labels": ctx.labels(0).tobytes(), "n_segments": int(c.n_segments),
+            "n_clusters": int(c.n_clusters), "n_planes": int(c.n_planes)}
+
+
+def test_clustering_partitioned_by_z_band(oracle_lib):
+    """north_star: "clustering is then partitioned by z-band, since bands are independent, and results are gathered
+    on rank 0".  A scene with empty z layers between its surfaces: the bands are cut there, every rank grows and
+    verifies the clusters of its own band only (the oracle checks the k-NN rows it is handed), and rank 0's merged
+    records and labels are those of one process -- on 2 and on 3 ranks.  With the band path switched off the same
+    scene gives the same result through the replicated path."""
+    xyz = _layer_cloud()
+    single = _single_result(oracle_lib, xyz)
+    assert single["n_planes"] >= 4
+    for world in (2, 3):
+        got = _run_ranks(world, 32500 + (os.getpid() % 2000) + world, layered=True)
+        assert [g[4] for g in got] == ["z-bands"] * world
+        assert got[0][5] == single and all(g[5] is None for g in got[1:])
+        assert sum(1 for v in got[0][6] if v > 0) >= 2          # at least two ranks really own fit points
+    got = _run_ranks(2, 32600 + (os.getpid() % 2000), layered=True, allow_bands=False)
+    assert [g[4] for g in got] == ["replicated"] * 2 and all(g[5] == single for g in got)
+
+
+def test_bands_without_empty_layers_fall_back(oracle_lib):
+    """A ramp populates every z layer and its neighbours link across all of them: no legal cut exists, edges cross
+    the equal-population cuts, and the call reports the replicated path with the single-process result on every
+    rank.  The multi-level scene (sparse at this size: some layers are empty) takes whichever path its k-NN rows
+    allow; rank 0 holds the single-process result either way."""
+    single = _single_result(oracle_lib, _ramp_cloud())
+    assert single["n_clusters"] >= 1
+    got = _run_ranks(3, 32700 + (os.getpid() % 2000), layered="ramp")
+    assert [g[4] for g in got] == ["replicated"] * 3 and all(g[5] == single for g in got)
+    single = _single_result(oracle_lib, _cloud())
+    got = _run_ranks(3, 32800 + (os.getpid() % 2000))
+    assert got[0][5] == single and got[0][4] in ("replicated", "z-bands")
 
 
 def test_band_partition():
@@ -98,6 +181,11 @@ def test_band_partition():
     for world in (1, 2, 3, 8):
         own = band_partition(hist, world)
         assert own.min() >= 0 and own.max() < world and np.all(np.diff(own) >= 0)
+        for k in np.nonzero(np.diff(own))[0]:                 # every cut has an empty layer on one side
+            assert hist[k] == 0 or hist[k + 1] == 0
+    assert band_partition(hist, 2).tolist() == [0] * 5 + [1] * 5 or band_partition(hist, 2).tolist() == [0] * 6 + [1] * 4
+    dense = np.array([10, 10, 10, 10], np.int64)              # no empty layer: equal population
+    assert band_partition(dense, 2).tolist() == [0, 0, 1, 1]
     assert band_partition(np.zeros(4, np.int64), 4).tolist() == [0, 0, 0, 0]
 
 
@@ -123,6 +211,14 @@ def test_one_cloud_on_two_ranks_matches_one_process(oracle_lib):
         for p in procs:
             p.join(timeout=60)
             assert p.exitcode == 0
-        for rank, summ, sent, received in got:
-            assert summ == single, rank                      # every rank ends with the whole-cloud result
+        for rank, summ, sent, received, path, res, own_fit in got:
             assert sum(sent) > 0 and min(received) > 0       # both bands are populated: points really moved
+            for k in ("n_raw", "n_vox", "n_fit", "grid", "min_b", "sha_downsampled", "sha_normals", "sha_fit_indices"):
+                assert summ[k] == single[k], (rank, k)        # A1..A8 of the whole cloud on every rank
+            if path == "replicated":
+                assert summ == single, rank                   # ... and A9..A12 too
+        # rank 0 holds the merged result on either path
+        want = {"clusters": ctx.clusters(0).tobytes(), "labels": ctx.labels(0).tobytes(),
+                "n_segments": int(ctx.counts(0).n_segments), "n_clusters": int(ctx.counts(0).n_clusters),
+                "n_planes": int(ctx.counts(0).n_planes)}
+        assert [g[5] for g in got if g[0] == 0][0] == want

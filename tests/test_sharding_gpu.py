@@ -1,7 +1,8 @@
 """One cloud across two ranks with the HIP library on both (the two processes share cuda:0; the exchanges
 go over gloo with host tensors): the whole multi-rank orchestration of hope_amd.sharding -- bounding-box and
 histogram all-reduces, the all-to-all by z band, the gathered VoxelGrid output, A6 and A8 shared by band
-through hope_segment_downsampled_staged -- must end, on every rank, with the oracle's single-process result."""
+through hope_segment_downsampled_staged, and A9..A12 either per z band (bands cut at empty layers, records
+merged on rank 0) or replicated (edges cross the cuts) -- must end with the oracle's single-process result."""
 import os
 import sys
 
@@ -11,10 +12,12 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from conftest import ROOT
-from test_sharding_cpu import _cloud
+from test_sharding_cpu import _cloud, _layer_cloud, _ramp_cloud, _single_result
+
+SCENES = {"multilevel": lambda: _cloud(120000), "layers": _layer_cloud, "ramp": _ramp_cloud}
 
 
-def _gpu_cloud_worker(rank, world, port, q):
+def _gpu_cloud_worker(rank, world, port, q, scene):
     import torch
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -24,34 +27,48 @@ def _gpu_cloud_worker(rank, world, port, q):
     from hope_amd.capi import HopeContext, HopeLib
     from hope_amd.sharding import frame_partition, segment_cloud_sharded
     from parity import summary
-    xyz = _cloud(120000)
+    xyz = SCENES[scene]()
     lo, hi = frame_partition(xyz.shape[0], world, rank)
     ctx = HopeContext(HopeLib())
     info = segment_cloud_sharded(ctx, torch.from_numpy(xyz[lo:hi].copy()), dist)
     dist.barrier()
-    q.put((rank, summary(ctx, 0), info["own_vox"], info["own_fit"]))
+    res = info["result"]
+    if res is not None:
+        res = {"clusters": np.asarray(res["clusters"]).tobytes(), "labels": np.asarray(res["labels"]).tobytes(),
+               "n_segments": res["n_segments"], "n_clusters": res["n_clusters"], "n_planes": res["n_planes"]}
+    q.put((rank, summary(ctx, 0), info["own_vox"], info["own_fit"], info["path"], res))
     dist.destroy_process_group()
 
 
 @pytest.mark.gpu
-def test_one_cloud_on_two_ranks_hip(oracle_lib):
+@pytest.mark.parametrize("scene,path", [("multilevel", None), ("layers", "z-bands"), ("ramp", "replicated")])
+def test_one_cloud_on_two_ranks_hip(oracle_lib, scene, path):
     from hope_amd.capi import HopeContext
     from parity import summary
-    xyz = _cloud(120000)
+    xyz = SCENES[scene]()
     ref = HopeContext(oracle_lib)
     ref.segment_cloud(xyz)
     single = summary(ref, 0)
-    assert single["n_planes"] > 0
+    want = _single_result(oracle_lib, xyz)
+    assert single["n_clusters"] > 0
     mpctx = mp.get_context("spawn")
     q = mpctx.Queue()
-    port = 33500 + (os.getpid() % 2000)
-    procs = [mpctx.Process(target=_gpu_cloud_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 33500 + (os.getpid() % 2000) + len(scene)
+    procs = [mpctx.Process(target=_gpu_cloud_worker, args=(r, 2, port, q, scene)) for r in range(2)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=240) for _ in range(2)]
+    got = sorted([q.get(timeout=240) for _ in range(2)], key=lambda g: g[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, summ, own_vox, own_fit in got:
-        assert summ == single, rank
-        assert min(own_vox) > 0 and sum(own_fit) == single["n_fit"]   # both bands did part of A6 and A8
+    for rank, summ, own_vox, own_fit, got_path, res in got:
+        for k in ("n_raw", "n_vox", "n_fit", "grid", "min_b", "sha_downsampled", "sha_normals", "sha_fit_indices"):
+            assert summ[k] == single[k], (rank, k)                        # A1..A7 of the whole cloud on every rank
+        assert sum(own_fit) == single["n_fit"]
+        if path is not None:
+            assert got_path == path
+        if got_path == "replicated":
+            assert summ == single, rank
+    assert got[0][5] == want                                               # the merged records and labels, rank 0
+    if scene != "ramp":
+        assert min(got[0][2]) > 0                                          # both bands did part of A6 and A8

@@ -95,8 +95,9 @@ def sharded(args):
         c = ctx.counts(0)
         print(json.dumps({"kind": "multilevel-sharded", "points": args.points, "n_gpus": world,
                           "ms_per_cloud": float(el.item()) * 1e3, "points_per_s": args.points / float(el.item()),
-                          "n_raw": c.n_raw, "n_vox": c.n_vox, "n_fit": c.n_fit, "n_clusters": c.n_clusters,
-                          "n_planes": c.n_planes, "sent_by_rank0": info["sent"], "received_by_rank0": info["received"]}))
+                          "n_raw": c.n_raw, "n_vox": c.n_vox, "n_fit": c.n_fit, "path": info["path"],
+                          "n_clusters": info["result"]["n_clusters"], "n_planes": info["result"]["n_planes"],
+                          "sent_by_rank0": info["sent"], "received_by_rank0": info["received"]}))
     dist.barrier()
     dist.destroy_process_group()
 
