@@ -79,24 +79,26 @@ HOPE_HD double hope_det_atan2(double y, double x)
 }
 
 /* cos / sin for |x| <= pi/2 (computeRoots only needs [0, pi/3]); nested Maclaurin
- * series whose denominators (2k-1)(2k) / (2k)(2k+1) are exact small integers. */
+ * series.  The coefficients 1 / ((2k-1)(2k)) and 1 / ((2k)(2k+1)) are compile-time constants (the
+ * correctly rounded doubles, the same on host and device): a multiplication each, no division --
+ * 26 double-precision divisions per normal were a third of k_normals_tile's instructions. */
 HOPE_HD double hope_det_cos(double x)
 {
   const double z = x * x;
   double p = 1.0;
-  p = 1.0 - z / 650.0 * p; /* 25*26 */
-  p = 1.0 - z / 552.0 * p; /* 23*24 */
-  p = 1.0 - z / 462.0 * p;
-  p = 1.0 - z / 380.0 * p;
-  p = 1.0 - z / 306.0 * p;
-  p = 1.0 - z / 240.0 * p;
-  p = 1.0 - z / 182.0 * p;
-  p = 1.0 - z / 132.0 * p;
-  p = 1.0 - z / 90.0 * p;
-  p = 1.0 - z / 56.0 * p;
-  p = 1.0 - z / 30.0 * p;
-  p = 1.0 - z / 12.0 * p;
-  p = 1.0 - z / 2.0 * p;
+  p = 1.0 - z * (1.0 / 650.0) * p; /* 25*26 */
+  p = 1.0 - z * (1.0 / 552.0) * p; /* 23*24 */
+  p = 1.0 - z * (1.0 / 462.0) * p;
+  p = 1.0 - z * (1.0 / 380.0) * p;
+  p = 1.0 - z * (1.0 / 306.0) * p;
+  p = 1.0 - z * (1.0 / 240.0) * p;
+  p = 1.0 - z * (1.0 / 182.0) * p;
+  p = 1.0 - z * (1.0 / 132.0) * p;
+  p = 1.0 - z * (1.0 / 90.0) * p;
+  p = 1.0 - z * (1.0 / 56.0) * p;
+  p = 1.0 - z * (1.0 / 30.0) * p;
+  p = 1.0 - z * (1.0 / 12.0) * p;
+  p = 1.0 - z * (1.0 / 2.0) * p;
   return p;
 }
 
@@ -104,19 +106,19 @@ HOPE_HD double hope_det_sin(double x)
 {
   const double z = x * x;
   double p = 1.0;
-  p = 1.0 - z / 702.0 * p; /* 26*27 */
-  p = 1.0 - z / 600.0 * p; /* 24*25 */
-  p = 1.0 - z / 506.0 * p;
-  p = 1.0 - z / 420.0 * p;
-  p = 1.0 - z / 342.0 * p;
-  p = 1.0 - z / 272.0 * p;
-  p = 1.0 - z / 210.0 * p;
-  p = 1.0 - z / 156.0 * p;
-  p = 1.0 - z / 110.0 * p;
-  p = 1.0 - z / 72.0 * p;
-  p = 1.0 - z / 42.0 * p;
-  p = 1.0 - z / 20.0 * p;
-  p = 1.0 - z / 6.0 * p;
+  p = 1.0 - z * (1.0 / 702.0) * p; /* 26*27 */
+  p = 1.0 - z * (1.0 / 600.0) * p; /* 24*25 */
+  p = 1.0 - z * (1.0 / 506.0) * p;
+  p = 1.0 - z * (1.0 / 420.0) * p;
+  p = 1.0 - z * (1.0 / 342.0) * p;
+  p = 1.0 - z * (1.0 / 272.0) * p;
+  p = 1.0 - z * (1.0 / 210.0) * p;
+  p = 1.0 - z * (1.0 / 156.0) * p;
+  p = 1.0 - z * (1.0 / 110.0) * p;
+  p = 1.0 - z * (1.0 / 72.0) * p;
+  p = 1.0 - z * (1.0 / 42.0) * p;
+  p = 1.0 - z * (1.0 / 20.0) * p;
+  p = 1.0 - z * (1.0 / 6.0) * p;
   return x * p;
 }
 
