@@ -51,7 +51,7 @@ struct Globals {  // scalars produced on device, read back at the sync points
   unsigned int n_vox_total;
   unsigned int pad;
   unsigned int n_groups;  // depth path: number of (chunk, voxel) group records
-  unsigned int max_tiles; // largest per-frame count of 16x16-column tiles (neighbours.hpp)
+  unsigned int max_tiles; // largest per-frame count of 32x32-column super tiles (neighbours.hpp)
   unsigned int total_ccols;  // entries of the coarse column table
   unsigned int n_todo;       // k-NN queries left over by the tile pass
   unsigned int max_fit;      // largest per-frame count of fit points
@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(1024) k_frame_grid(FrameInfo* fi, int n_frames
           atomicMax(&s_max_dz, (unsigned)div_b[2]);
           ncols = (unsigned)(div_b[0] * div_b[1]) + 1u;
           nccols = (unsigned)(((div_b[0] + kCoarse - 1) / kCoarse) * ((div_b[1] + kCoarse - 1) / kCoarse)) + 1u;
-          atomicMax(&s_max_tiles, (unsigned)(((div_b[0] + 15) / 16) * ((div_b[1] + 15) / 16)));
+          atomicMax(&s_max_tiles, (unsigned)(((div_b[0] + 31) / 32) * ((div_b[1] + 31) / 32)));  // (neighbours.hpp: kSuper)
         }
       }
       for (int d = 0; d < 3; ++d) {

@@ -20,6 +20,10 @@
 namespace hope {
 
 constexpr int kTile = 16;                  // interior columns per tile side
+constexpr int kSuper = 32;                 // a workgroup owns a 32x32-column super tile: taken whole when its points fit
+                                           // in LDS (a depth frame's surfaces fill a fraction of their xy bounding box: a
+                                           // 16x16 tile holds ~70 points, too few for 256 threads), else as its four tiles
+constexpr int kSlabSide = 8;               // largest region loaded as a z slab
 constexpr int kHaloNormals = 2;            // halo columns on each side: the normal radius reaches 2 columns
 constexpr int kHaloKnn = 4;                // k-NN: rings 0..4 are served from LDS
 constexpr int kTileCap = 1536;             // points (tile + halo) held in LDS: 24 KiB
@@ -58,7 +62,7 @@ typedef GlobalColsT<true> CoarseCols;
 
 template <int HALO>
 struct TileCols {  // LDS copy of a tile and its halo
-  static constexpr int kTabStride = kTile + 2 * HALO + 1;  // per row: the column starts + the row end
+  static constexpr int kTabStride = kSuper + 2 * HALO + 1;  // per row: the column starts + the row end
   const float4* s_pt;
   const unsigned* s_tab;
   int xh0, yh0;
@@ -81,15 +85,16 @@ struct TileCols {  // LDS copy of a tile and its halo
 
 template <bool WITH_FIT, int HALO>
 struct TileShared {
-  static constexpr int kTW = kTile + 2 * HALO;
+  static constexpr int kTW = kSuper + 2 * HALO;
   static constexpr int kTabStride = kTW + 1;
+  static constexpr int kSlabW = kSlabSide + 2 * HALO;
   float4 pt[kTileCap];  // WITH_FIT: .w holds the fit rank (int bits) instead of the PCL-order index
   unsigned tab[kTW * kTabStride];
   unsigned rowg[kTW + 1];   // global start of each halo row segment
   unsigned rowl[kTW + 1];   // local start (prefix of segment sizes)
-  unsigned intg[kTile + 1]; // global start of each interior row segment
-  unsigned intp[kTile + 1]; // prefix of interior row sizes
-  unsigned colg[kTW * kTW]; // slab mode: global start of the slab part of each column
+  unsigned intg[kSuper + 1]; // global start of each interior row segment
+  unsigned intp[kSuper + 1]; // prefix of interior row sizes
+  unsigned colg[kSlabW * kSlabW]; // slab mode (regions of at most kSlabSide columns a side): global start of the slab part of each column
   unsigned zext[2];         // slab mode: ordered-int min / max z of the region
   unsigned total;
   unsigned nlist;           // slab mode: the interior points of the copy, compacted
@@ -164,7 +169,7 @@ __device__ __forceinline__ bool load_tile(const FrameInfo& F, int x0, int y0, in
       S.intp[r] = acc;
       acc += c;
     }
-    for (int r = irows; r <= kTile; ++r) S.intp[r] = acc;  // (padded: interior_point searches all kTile rows)
+    for (int r = irows; r <= kSuper; ++r) S.intp[r] = acc;  // (padded: interior_point searches all kSuper rows)
   }
   __syncthreads();
   g.total = S.rowl[rows];
@@ -194,8 +199,9 @@ template <bool WITH_FIT, int HALO>
 __device__ __forceinline__ void interior_point(const TileShared<WITH_FIT, HALO>& S, const TileGeom& g, unsigned i,
                                                unsigned& e_glob, unsigned& e_loc)
 {
-  static_assert(kTile == 16, "four-step search over the interior rows");
+  static_assert(kSuper == 32, "five-step search over the interior rows");
   int r = 0;  // last row whose first point is <= i (rows past the tile's last hold the total)
+  if (S.intp[r + 16] <= i) r += 16;
   if (S.intp[r + 8] <= i) r += 8;
   if (S.intp[r + 4] <= i) r += 4;
   if (S.intp[r + 2] <= i) r += 2;
@@ -324,7 +330,8 @@ __device__ __forceinline__ void load_slab(const FrameInfo& F, float zlo_h, float
   __syncthreads();
 }
 
-// Walks the regions of one 16x16 tile that fit in LDS, one per call of next():
+// Walks the regions of one 32x32 super tile that fit in LDS, one per call of next():
+//   * the whole super tile with its halo, every z, else each of its four 16x16 tiles:
 //   * the whole tile with its halo, every z (horizontal surfaces: a few points per column), else
 //   * its 8x8 quarters, every z (noisy far range: several z layers per column), and a quarter
 //     that still does not fit
@@ -342,9 +349,10 @@ struct TileWalker {
   TileShared<WITH_FIT, HALO>& S;
   int halo_xy;   // xy halo of the slab regions (<= HALO)
   float zhalo, leaf_z;
-  int X0, Y0;
-  int stage = 0, a = 0, b = 0;
-  bool in8 = false, in4 = false, in4walk = false;
+  int SX, SY;    // the super tile
+  int X0 = 0, Y0 = 0;  // the current 16x16 tile
+  int stage = 0, a = 0, b = 0, sub = 0;
+  bool in8 = false, in4 = false, in4walk = false, in16 = false;
   int x8 = 0, y8 = 0, x4 = 0, y4 = 0, h8 = 1, h4 = 1;
   float z8 = 0.f, zend8 = 0.f, zs8 = 0.f, ze8 = 0.f, z4 = 0.f, zend4 = 0.f;
 
@@ -354,10 +362,10 @@ struct TileWalker {
       : F(F_), spt(spt_), col_first(col_first_), fit_rank(fit_rank_), S(S_), halo_xy(halo_xy_), zhalo(zhalo_),
         leaf_z(leaf_z_)
   {
-    const int ntx = (F.div_b[0] + kTile - 1) / kTile;
+    const int ntx = (F.div_b[0] + kSuper - 1) / kSuper;
     const int ty = tile / ntx;
-    X0 = (tile - ty * ntx) * kTile;
-    Y0 = ty * kTile;
+    SX = (tile - ty * ntx) * kSuper;
+    SY = ty * kSuper;
   }
 
   // slab height (cells) from the mean number of points per z layer of the region
@@ -380,7 +388,7 @@ struct TileWalker {
     for (int guard = 0; guard < (1 << 22); ++guard) {
       if (stage == 0) {
         stage = 1;
-        if (!load_tile<WITH_FIT, HALO>(F, X0, Y0, kTile, spt, col_first, fit_rank, S, g)) break;
+        if (!load_tile<WITH_FIT, HALO>(F, SX, SY, kSuper, spt, col_first, fit_rank, S, g)) break;
         if (g.in_lds) {
           stage = 2;
           return true;
@@ -388,6 +396,19 @@ struct TileWalker {
         continue;
       }
       if (stage == 2) break;
+      if (!in16) {
+        // the next 16x16 tile of the super tile
+        if (sub == 4) break;
+        X0 = SX + (sub & 1) * kTile;
+        Y0 = SY + (sub >> 1) * kTile;
+        ++sub;
+        if (X0 >= F.div_b[0] || Y0 >= F.div_b[1]) continue;
+        if (!load_tile<WITH_FIT, HALO>(F, X0, Y0, kTile, spt, col_first, fit_rank, S, g)) continue;
+        if (g.in_lds) return true;
+        in16 = true;  // it does not fit: its quarters
+        a = 0;
+        continue;
+      }
       if (in4) {
         if (!in4walk) {
           if (b == 4) {
@@ -458,7 +479,10 @@ struct TileWalker {
         if (g.total == 0) continue;
         return true;
       }
-      if (a == 4) break;
+      if (a == 4) {
+        in16 = false;
+        continue;
+      }
       x8 = X0 + (a & 1) * 8;
       y8 = Y0 + (a >> 1) * 8;
       ++a;
@@ -766,7 +790,7 @@ k_normals_tile(const float4* spt, const uint32_t* col_first, const FrameInfo* fi
   __shared__ unsigned short s_cand_e[CAPL * kBlock];
   const FrameInfo& F = fi[blockIdx.y];
   const int dx = F.div_b[0], dy = F.div_b[1];
-  if (F.n_vox <= 0 || (int)blockIdx.x >= ((dx + kTile - 1) / kTile) * ((dy + kTile - 1) / kTile)) return;
+  if (F.n_vox <= 0 || (int)blockIdx.x >= ((dx + kSuper - 1) / kSuper) * ((dy + kSuper - 1) / kSuper)) return;
   const float leaf_z = 1.0f / inv_z;
   unsigned short* cand_e = s_cand_e + threadIdx.x;
   const GlobalCols gc{spt, col_first, nullptr, (unsigned)F.col_off, dx};
@@ -901,7 +925,7 @@ k_knn_tile(const float4* spt, const uint32_t* col_first, const int* fit_rank, co
   __shared__ TileShared<true, kHaloKnn> S;
   const FrameInfo& F = fi[blockIdx.y];
   const int dx = F.div_b[0], dy = F.div_b[1];
-  if (F.n_fit <= 0 || (int)blockIdx.x >= ((dx + kTile - 1) / kTile) * ((dy + kTile - 1) / kTile)) return;
+  if (F.n_fit <= 0 || (int)blockIdx.x >= ((dx + kSuper - 1) / kSuper) * ((dy + kSuper - 1) / kSuper)) return;
   const float leaf_z = 1.0f / inv_z;
   const int k = min(K, F.n_fit);
   // Fast pass: the 5x5 square is ring 2; a list that settles there holds only neighbours closer
