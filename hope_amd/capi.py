@@ -67,7 +67,7 @@ assert CLUSTER_DTYPE.itemsize == C.sizeof(HopeCluster)
 
 # every symbol include/hope_gpu.h declares (without prefix)
 ABI_SYMBOLS = [
-    "config_default", "create", "destroy", "last_error", "set_pose", "set_frame_poses",
+    "config_default", "create", "destroy", "last_error", "set_pose", "set_pose_rpy", "set_frame_poses",
     "set_height_window", "segment_depth_u16", "segment_cloud_xyz", "num_frames",
     "frame_counts", "get_transformed", "get_downsampled", "get_normals", "get_fit_indices",
     "get_knn", "get_labels", "get_clusters", "get_cluster_indices", "get_max_plane", "get_max_plane_members",
@@ -100,6 +100,7 @@ class HopeLib:
             "destroy": (None, [vp]),
             "last_error": (C.c_char_p, [vp]),
             "set_pose": (C.c_int, [vp, f32p, f32p]),
+            "set_pose_rpy": (C.c_int, [vp, C.c_float, C.c_float, C.c_float]),
             "set_frame_poses": (C.c_int, [vp, i32, f32p, f32p]),
             "set_height_window": (C.c_int, [vp, C.c_float, C.c_float]),
             "segment_depth_u16": (C.c_int, [vp, vp, i32, i32, i32, i32]),
@@ -214,6 +215,10 @@ class HopeContext:
         assert t.shape == (3,) and q.shape == (4,)
         fp = C.POINTER(C.c_float)
         self._check(self.lib.fn["set_pose"](self._h, t.ctypes.data_as(fp), q.ctypes.data_as(fp)), "set_pose")
+
+    def set_pose_rpy(self, roll, pitch, yaw):
+        """PlaneSegment::setRPY + the roll/pitch/yaw doTransform (transform.cpp:108-130); radians."""
+        self._check(self.lib.fn["set_pose_rpy"](self._h, float(roll), float(pitch), float(yaw)), "set_pose_rpy")
 
     def set_frame_poses(self, t, q):
         t, q = _f32(t), _f32(q)

@@ -1250,6 +1250,20 @@ HOPE_API int hope_set_pose(hope_ctx* c, const float t[3], const float q[4])
   return HOPE_OK;
 }
 
+// The pose Transform::doTransform(cloud, out, roll, pitch, yaw) builds (transform.cpp:108-130): translation
+// (0, 0, 1) m (transform.cpp:4-6), rotation tf2's setRPY in double with y negated, narrowed to float.
+HOPE_API int hope_set_pose_rpy(hope_ctx* c, float roll, float pitch, float yaw)
+{
+  if (!c) return HOPE_E_INVALID;
+  const double hr = 0.5 * (double)roll, hp = 0.5 * (double)pitch, hy = 0.5 * (double)yaw;
+  const double cr = std::cos(hr), sr = std::sin(hr), cp = std::cos(hp), sp = std::sin(hp), cy = std::cos(hy),
+               sy = std::sin(hy);
+  const double x = sr * cp * cy - cr * sp * sy, y = cr * sp * cy + sr * cp * sy, z = cr * cp * sy - sr * sp * cy,
+               w = cr * cp * cy + sr * sp * sy;
+  const float t[3] = {0.f, 0.f, 1.f}, q[4] = {(float)x, (float)-y, (float)z, (float)w};
+  return hope_set_pose(c, t, q);
+}
+
 HOPE_API int hope_set_frame_poses(hope_ctx* c, int n, const float* t, const float* q)
 {
   if (!c || n < 0 || (n > 0 && (!t || !q))) return HOPE_E_INVALID;

@@ -116,10 +116,28 @@ int main(int argc, char** argv)
     std::string err;
 
     if (type == SYN) {
-      hope.setRPY(roll, pitch, yaw);
+      hope.setRPY(roll, pitch, yaw);                                                      // hope_node.cpp:169
+      // Upstream the synthetic object's cloud arrives on a ROS topic (plane_segment.cpp:604-622).  Without ROS the
+      // message is a .pcd/.ply file named by HOPE_NODE_SYN_CLOUD, handed to the same cloudCallback.
+      const char* syn = std::getenv("HOPE_NODE_SYN_CLOUD");
       PointCloud::Ptr none(new PointCloud);
-      hope.getHorizontalPlanes(none);          // refuses: the synthetic object arrives over a ROS topic upstream
-      return 2;
+      if (!syn) {
+        hope.getHorizontalPlanes(none);          // refuses: no cloud source
+        return 2;
+      }
+      PointCloud::Ptr msg(new PointCloud);
+      const std::string path = syn;
+      const bool is_ply = path.size() > 4 && path.compare(path.size() - 4, 4, ".ply") == 0;
+      if (!(is_ply ? readPly(path, *msg, err) : readPcd(path, *msg, err))) {
+        std::cerr << "Couldn't read " << path << ". (" << err << ")" << std::endl;
+        return -1;
+      }
+      hope.cloudCallback(msg);
+      hope.getHorizontalPlanes(none);
+      if (hope.last_status() < 0) return 1;
+      report(hope, path, dump);
+      std::printf("[TIMER]: total: %.3f ms (whole call %.3f ms)\n", hope.last_timer_window_ms(), hope.last_ms());
+      return 0;
     }
     if (type == POINT_CLOUD) {
       PointCloud::Ptr src_cloud(new PointCloud);

@@ -117,9 +117,17 @@ bool PlaneSegment::collect(int frame)
 void PlaneSegment::getHorizontalPlanes(PointCloud::Ptr cloud)
 {
   if (type_ == SYN) {
-    // plane_segment.cpp:113-117 waits for a cloud on a ROS topic; there is no ROS here.
-    std::cerr << "PlaneSegment: SYN mode needs the ROS cloud source, which this build does not have." << std::endl;
-    last_status_ = HOPE_E_INVALID;
+    // plane_segment.cpp:113-117 spins until the subscriber's cloudCallback (:604-622) has delivered a cloud; there is
+    // no ROS here, so the caller delivers it through cloudCallback and this call consumes it.
+    if (!syn_cloud_) {
+      std::cerr << "PlaneSegment: SYN mode has no source cloud yet (cloudCallback has not run)." << std::endl;
+      last_status_ = HOPE_E_INVALID;
+      return;
+    }
+    PointCloud::ConstPtr src = syn_cloud_;
+    syn_cloud_.reset();
+    hope_set_pose_rpy(ctx_, roll_, pitch_, yaw_);                                                                // :620
+    afterCall(hope_segment_cloud_xyz(ctx_, src->points.data(), src->points.size(), sizeof(PointXYZRGB), 1, 0)); // :617-621
     return;
   }
   if (!cloud) { last_status_ = HOPE_E_INVALID; return; }
@@ -132,6 +140,12 @@ void PlaneSegment::getHorizontalPlanes(PointCloud::Ptr cloud)
     st = hope_segment_cloud_xyz(ctx_, cloud->points.data(), cloud->points.size(), sizeof(PointXYZRGB), 1, 0);   // :123-127
   }
   afterCall(st);
+}
+
+void PlaneSegment::cloudCallback(const PointCloud::ConstPtr& src_temp)
+{
+  if (!src_temp || src_temp->empty()) { std::cerr << "HoPE: PointCloud is empty." << std::endl; return; }       // :606-609
+  syn_cloud_ = src_temp;
 }
 
 void PlaneSegment::getHorizontalPlanes(const uint16_t* depth, int width, int height)

@@ -49,6 +49,11 @@ class PlaneSegment {
   PointCloud::Ptr plane_max_hull_;
   std::vector<float> plane_max_coeff_;
 
+  // SYN mode's cloud source (plane_segment.cpp:604-622): upstream a ROS subscriber hands the message to
+  // cloudCallback; here the caller does.  The next getHorizontalPlanes(any) range-filters the sensor-frame
+  // cloud and transforms it with the setRPY angles (transform.cpp:108-150, hope_set_pose_rpy).
+  void cloudCallback(const PointCloud::ConstPtr& src_temp);
+
   void setRPY(float roll = 0.0, float pitch = 0.0, float yaw = 0.0);
   void setQ(float qx = 0.0, float qy = 0.0, float qz = 0.0, float qw = 1.0);
   void setT(float tx = 0.0, float ty = 0.0, float tz = 0.0);
@@ -69,6 +74,7 @@ class PlaneSegment {
   float qx_ = 0.f, qy_ = 0.f, qz_ = 0.f, qw_ = 1.f;
   float tx_ = 0.f, ty_ = 0.f, tz_ = 0.f;
   std::string base_frame_;
+  PointCloud::ConstPtr syn_cloud_;          // SYN: the cloud of the last cloudCallback, consumed by the next call
   PlaneIdTracker ids_;
   hope_ctx* ctx_ = nullptr;
   hope_counts counts_{};

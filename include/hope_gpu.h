@@ -130,6 +130,11 @@ HOPE_API const char* hope_last_error(const hope_ctx* ctx);
  * consumed by Transform::doTransform (transform.cpp:72-98); quaternion is NOT normalised,
  * exactly like the reference. Applies to every frame. */
 HOPE_API int hope_set_pose(hope_ctx* ctx, const float t_xyz[3], const float q_xyzw[4]);
+/* replaces PlaneSegment::setRPY (plane_segment.cpp:86-91) + the roll/pitch/yaw overload of
+ * Transform::doTransform (transform.cpp:108-130) that the SYN cloud callback applies (plane_segment.cpp:620):
+ * translation (0, 0, 1) m (transform.cpp:4-6), rotation tf2::Quaternion::setRPY in double with y negated
+ * (transform.cpp:117-118), narrowed to float. Angles in radians. Applies to every frame, like hope_set_pose. */
+HOPE_API int hope_set_pose_rpy(hope_ctx* ctx, float roll, float pitch, float yaw);
 /* per-frame poses for a depth batch (the TUM_LIST loop, hope_node.cpp:228-241) */
 HOPE_API int hope_set_frame_poses(hope_ctx* ctx, int n_frames, const float* t_xyz,
                                   const float* q_xyzw);

@@ -959,6 +959,27 @@ ORACLE_API int hope_oracle_set_pose(hope_ctx* ctx, const float t[3], const float
   return HOPE_OK;
 }
 
+// transform.cpp:108-130: the pose of the roll/pitch/yaw overload of doTransform.  The translation is the file's
+// camera-to-base constants (transform.cpp:4-6: 0, 0, 1 m); the rotation is tf2::Quaternion::setRPY (geometry2,
+// tf2/LinearMath/Quaternion.h -- a ROS dependency that is not part of the reference tree; its published formula is
+// restated here in tf2Scalar = double, with libm's cos/sin as tf2Cos/tf2Sin are), then y is negated (:118) and the
+// four doubles are narrowed to float by Eigen::Quaternion<float>(w, x, y, z) (:130).
+ORACLE_API int hope_oracle_set_pose_rpy(hope_ctx* ctx, float roll, float pitch, float yaw)
+{
+  if (!ctx) return HOPE_E_INVALID;
+  const double half_yaw = (double)yaw * 0.5, half_pitch = (double)pitch * 0.5, half_roll = (double)roll * 0.5;
+  const double cy = std::cos(half_yaw), sy = std::sin(half_yaw);
+  const double cp = std::cos(half_pitch), sp = std::sin(half_pitch);
+  const double cr = std::cos(half_roll), sr = std::sin(half_roll);
+  const double qx = sr * cp * cy - cr * sp * sy;
+  const double qy = cr * sp * cy + sr * cp * sy;
+  const double qz = cr * cp * sy - sr * sp * cy;
+  const double qw = cr * cp * cy + sr * sp * sy;
+  const float t[3] = {0.f, 0.f, 1.0f};
+  const float q[4] = {(float)qx, (float)(-qy), (float)qz, (float)qw};
+  return hope_oracle_set_pose(ctx, t, q);
+}
+
 ORACLE_API int hope_oracle_set_frame_poses(hope_ctx* ctx, int n, const float* t, const float* q)
 {
   if (!ctx || n < 0 || (n > 0 && (!t || !q))) return HOPE_E_INVALID;

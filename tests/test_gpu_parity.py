@@ -107,6 +107,20 @@ def test_cloud_with_filter_and_pose(hip_lib, oracle_lib):
         assert_frame_equal(o, g, 0, check_transformed=True)
 
 
+def test_rpy_pose(hip_lib, oracle_lib):
+    """hope_set_pose_rpy: the roll/pitch/yaw doTransform of the SYN cloud callback (transform.cpp:108-130,
+    plane_segment.cpp:617-621)."""
+    from test_oracle import rpy_scene
+    for rpy in ((0.3, -0.2, 0.5), (-1.1, 0.4, 2.9), (0.0, 0.0, 0.0)):
+        xyz = rpy_scene(*rpy)
+        g, o = both(hip_lib, oracle_lib)
+        for c in (g, o):
+            c.set_pose_rpy(*rpy)
+            c.segment_cloud(xyz, apply_filter_transform=True)
+        assert o.counts(0).n_planes >= 1
+        assert_frame_equal(o, g, 0, check_transformed=True)
+
+
 def test_multilevel_scene_cloud(hip_lib, oracle_lib):
     """Config-4 shaped input at a size the oracle finishes in seconds."""
     from hope_amd import synth

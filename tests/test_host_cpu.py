@@ -327,7 +327,7 @@ def test_hope_node_list_mode_and_argument_counts(test_bins, oracle_lib, tmp_path
     r, _ = run_node(test_bins[0], ["a", "b", "c", "d", "e"], tmp_path)
     assert r.returncode == 255 and "hope_node VARIABLES" in r.stdout
     r, _ = run_node(test_bins[0], ["0", "0", "0"], tmp_path)
-    assert r.returncode == 2 and "Using synthetic object." in r.stdout
+    assert r.returncode == 2 and "Using synthetic object." in r.stdout and "no source cloud" in r.stderr
     r, _ = run_node(test_bins[0], [tmp_path / "none.xyz", "xyz"], tmp_path)
     assert r.returncode == 255 and "Unrecognized file format." in r.stderr
 
@@ -343,6 +343,26 @@ def test_hope_node_point_cloud_file(test_bins, oracle_lib, tmp_path):
     c = HopeContext(oracle_lib)
     c.segment_cloud(xyz, apply_filter_transform=False)
     check_record(recs[0], c.counts(0), [r_ for r_ in c.clusters(0) if r_["pass"] == 1])
+
+
+def test_hope_node_synthetic_mode_with_rpy(test_bins, oracle_lib, tmp_path, monkeypatch):
+    """`hope_node roll pitch yaw` (hope_node.cpp:129-135,169): the cloud of the (ROS) callback comes from a file; it is
+    range-filtered and transformed with the setRPY pose (plane_segment.cpp:617-621, transform.cpp:108-150)."""
+    from test_oracle import rpy_scene
+    rpy = (0.3, -0.2, 0.5)
+    xyz = rpy_scene(*rpy, n=40000)
+    p = tmp_path / "syn.ply"
+    p.write_bytes(("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+                   "end_header\n" % len(xyz)).encode() + xyz.tobytes())
+    monkeypatch.setenv("HOPE_NODE_SYN_CLOUD", str(p))
+    r, recs = run_node(test_bins[0], [repr(v) for v in rpy], tmp_path, hull=False)
+    assert r.returncode == 0, r.stderr
+    c = HopeContext(oracle_lib)
+    c.set_pose_rpy(*rpy)
+    c.segment_cloud(xyz, apply_filter_transform=True)
+    planes = [r_ for r_ in c.clusters(0) if r_["pass"] == 1]
+    assert len(planes) >= 3
+    check_record(recs[0], c.counts(0), planes)
 
 
 def test_rt_adapter(test_bins, oracle_lib, tum_example, tmp_path):

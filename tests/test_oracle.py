@@ -61,6 +61,56 @@ def test_transform_matches_float64_rotation(oracle_lib, tum_example):
     assert np.max(np.abs(xyz - ref) / np.maximum(np.abs(ref), 1.0)) < 1e-5
 
 
+def rpy_pose(roll, pitch, yaw):
+    """tf2::Quaternion::setRPY in double (libm through math), y negated, narrowed to float; translation (0, 0, 1):
+    the pose of transform.cpp:108-130, written independently of the libraries under test."""
+    import math
+    hr, hp, hy = 0.5 * float(np.float32(roll)), 0.5 * float(np.float32(pitch)), 0.5 * float(np.float32(yaw))
+    cr, sr, cp, sp, cy, sy = math.cos(hr), math.sin(hr), math.cos(hp), math.sin(hp), math.cos(hy), math.sin(hy)
+    q = [sr * cp * cy - cr * sp * sy, -(cr * sp * cy + sr * cp * sy), cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy]
+    return np.float32([0, 0, 1]), np.float32(q)
+
+
+def rpy_scene(roll, pitch, yaw, n=60000):
+    """A sensor-frame cloud that the roll/pitch/yaw pose brings back to a scene of horizontal surfaces."""
+    from hope_amd import synth
+    world = synth.make_multilevel_cloud(n, first_index=0, device="cpu").numpy().astype(np.float64) * 0.25 + [0, 0, 0.2]
+    t, q = rpy_pose(roll, pitch, yaw)
+    x, y, z, w = [float(v) for v in q]
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    return ((world - t.astype(np.float64)) @ R).astype(np.float32)     # R^T (p - t), row vectors
+
+
+def test_rpy_pose(oracle_lib):
+    """hope_set_pose_rpy (transform.cpp:108-130): known answers of tf2's setRPY, and the same results as
+    hope_set_pose with the quaternion computed here."""
+    pts = np.float32([[0.5, 0.25, 1.0], [-1.0, 2.0, 3.0], [0.125, -0.5, 0.75]])
+    c = HopeContext(oracle_lib)
+    c.set_pose_rpy(0.0, 0.0, 0.0)                                       # identity rotation: only the 1 m lift
+    c.segment_cloud(pts, apply_filter_transform=True)
+    assert np.array_equal(c.transformed(0)[0], pts + np.float32([0, 0, 1]))
+    c.set_pose_rpy(0.0, 0.0, np.pi / 2)                                 # yaw 90 deg: (x, y) -> (-y, x)
+    c.segment_cloud(pts, apply_filter_transform=True)
+    assert np.allclose(c.transformed(0)[0], np.stack([-pts[:, 1], pts[:, 0], pts[:, 2] + 1], 1), atol=1e-6)
+    c.set_pose_rpy(0.0, np.pi / 2, 0.0)                                 # pitch 90 deg with y negated: (x, z) -> (-z, x)
+    c.segment_cloud(pts, apply_filter_transform=True)
+    assert np.allclose(c.transformed(0)[0], np.stack([-pts[:, 2], pts[:, 1], pts[:, 0] + 1], 1), atol=1e-6)
+    c.set_pose_rpy(np.pi / 2, 0.0, 0.0)                                 # roll 90 deg: (y, z) -> (-z, y)
+    c.segment_cloud(pts, apply_filter_transform=True)
+    assert np.allclose(c.transformed(0)[0], np.stack([pts[:, 0], -pts[:, 2], pts[:, 1] + 1], 1), atol=1e-6)
+    rpy = (0.3, -0.2, 0.5)
+    xyz = rpy_scene(*rpy)
+    a, b = HopeContext(oracle_lib), HopeContext(oracle_lib)
+    a.set_pose_rpy(*rpy)
+    b.set_pose(*rpy_pose(*rpy))
+    for k in (a, b):
+        k.segment_cloud(xyz, apply_filter_transform=True)
+    assert_frame_equal(a, b, 0, check_transformed=True)
+    assert a.counts(0).n_planes >= 3                                    # the surfaces are horizontal again
+
+
 def test_against_committed_golden(oracle_lib, tum_example):
     g = golden()
     assert summary(run_example(oracle_lib, tum_example), 0) == g["tum_example"]
