@@ -535,7 +535,7 @@ int stage_voxel_rank(hope_ctx* c, const DepthSrc& src, size_t n_per_frame, size_
   ALLOC(d_vox, float4, n_vox);
   ALLOC(d_vox_frame, int, n_vox);
   pm = prof_mark(c);
-  const dim3 grid(c->h_glob->max_vox);  // (blocks of kBlock voxels, frame by frame)
+  const dim3 grid((c->h_glob->max_vox + kXcds - 1u) / kXcds * kXcds);  // (blocks of kBlock voxels, frame by frame; dealt to the XCDs by the kernel)
   if (c->fast_div)
     hipLaunchKernelGGL(k_centroids_lists<true>, grid, dim3(kBlock), 0, s, src, c->d_fi, F, block_first, c->cpf,
                        c->d_grp_off, rec_list, vox_end, c->d_slots, d_vox, d_vox_frame);

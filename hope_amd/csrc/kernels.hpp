@@ -471,6 +471,7 @@ k_voxel_keys_depth8(DepthSrc src, const FrameInfo* fi, float inv_xy, float inv_z
 // float sum as VoxelGrid's (voxel_grid.hpp).  A 2-D chunk meets fewer voxels than 64 pixels of
 // one row: 1.95x fewer records at 4x16 than at 1x64 on the synthetic frames.
 constexpr int kChunk = 64;
+constexpr unsigned kXcds = 8u;  // accelerator dies of an MI355X: workgroup i of a launch runs on XCD i % 8, each with its own L2
 constexpr int kChunkRows = 4;
 constexpr int kChunkCols = kChunk / kChunkRows;
 

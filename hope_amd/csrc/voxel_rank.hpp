@@ -311,16 +311,23 @@ k_centroids_lists(DepthSrc src, const FrameInfo* fi, int n_frames, const uint32_
                   int* vox_frame)
 {
   __shared__ unsigned s_list[kListCap];
-  // frame of this block: the last one whose first block is <= blockIdx.x (frames without voxels own no block)
+  // Workgroups are dealt to the eight XCDs in turn, and each XCD has its own L2.  The voxels of a frame share
+  // their depth lines and records with the voxels a few blocks on (the next row of cells), so the blocks of a
+  // frame belong on ONE XCD: XCD x takes the x-th eighth of the blocks, in order.
+  const unsigned n_blocks = block_first[n_frames];
+  const unsigned per_xcd = (n_blocks + kXcds - 1u) / kXcds;
+  const unsigned blk = (blockIdx.x % kXcds) * per_xcd + blockIdx.x / kXcds;
+  if (blk >= n_blocks) return;
+  // frame of this block: the last one whose first block is <= blk (frames without voxels own no block)
   int lo = 0, hi = n_frames;
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
-    if (block_first[mid] <= blockIdx.x) lo = mid; else hi = mid;
+    if (block_first[mid] <= blk) lo = mid; else hi = mid;
   }
   const int frame = lo;
   const FrameInfo& F = fi[frame];
   const unsigned n_vox = (unsigned)F.n_vox;
-  const unsigned v0 = (blockIdx.x - block_first[frame]) * kBlock;
+  const unsigned v0 = (blk - block_first[frame]) * kBlock;
   if (v0 >= n_vox) return;
   const unsigned rec_base = grp_off[(size_t)frame * cpf];
   const unsigned v = v0 + threadIdx.x;

@@ -6,7 +6,7 @@ O=$R/gpurun_out
 mkdir -p $O
 cd $R
 if [ -n "$2" ]; then K=(-k "$2"); else K=(); fi
-timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread "${K[@]}" > $O/pytest_$tag.log 2>&1
+timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 150 --timeout-method thread "${K[@]}" > $O/pytest_$tag.log 2>&1
 rc=$?
 tail -5 $O/pytest_$tag.log
 [ $rc -ne 0 ] && exit $rc
