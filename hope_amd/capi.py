@@ -70,7 +70,7 @@ ABI_SYMBOLS = [
     "config_default", "create", "destroy", "last_error", "set_pose", "set_pose_rpy", "set_frame_poses",
     "set_height_window", "segment_depth_u16", "segment_cloud_xyz", "num_frames",
     "frame_counts", "get_transformed", "get_downsampled", "get_normals", "get_fit_indices",
-    "get_knn", "get_labels", "get_clusters", "get_cluster_indices", "get_max_plane", "get_max_plane_members",
+    "get_knn", "get_labels", "get_clusters", "get_cluster_indices", "get_cluster_hull_candidates", "get_max_plane", "get_max_plane_members",
     "last_timing", "grid_from_bbox", "shard_bbox", "shard_z_histogram", "shard_route",
     "downsample_cloud_bbox", "segment_downsampled", "segment_downsampled_staged",
     "get_normals_rows", "get_knn_rows", "get_downsampled_to",
@@ -115,6 +115,7 @@ class HopeLib:
             "get_labels": (C.c_int, [vp, i32, vp]),
             "get_clusters": (C.c_int, [vp, i32, vp, i32]),
             "get_cluster_indices": (C.c_int, [vp, i32, i32, vp, i32]),
+            "get_cluster_hull_candidates": (C.c_int, [vp, i32, i32, vp, i32]),
             "get_max_plane": (C.c_int, [vp, i32, C.POINTER(HopeMaxPlane)]),
             "get_max_plane_members": (C.c_int, [vp, i32, vp, i32]),
             "last_timing": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -414,6 +415,13 @@ class HopeContext:
         got = self._check(self.lib.fn["get_cluster_indices"](self._h, frame, cluster, out.ctypes.data, size),
                           "get_cluster_indices")
         return out[:got]
+
+    def cluster_hull_candidates(self, frame, cluster, size):
+        """Positions in the cluster's member list of the points that can be hull vertices (F2)."""
+        out = np.empty(max(size, 1), np.int32)
+        n = self._check(self.lib.fn["get_cluster_hull_candidates"](self._h, frame, cluster, out.ctypes.data, size),
+                        "get_cluster_hull_candidates")
+        return out[:min(n, size)]
 
     def max_plane(self, frame=0):
         m = HopeMaxPlane()

@@ -19,6 +19,7 @@
 #include "prims.hpp"
 #include "upon_plane.hpp"
 #include "voxel_rank.hpp"
+#include "hull.hpp"
 
 using namespace hope;
 
@@ -218,6 +219,7 @@ struct hope_ctx {
   int* d_knn = nullptr;
   int* d_cid = nullptr;
   uint32_t* d_members = nullptr;
+  const float4* d_fit_pt = nullptr;  // fit points in fit order (the members index it)
   uint32_t* d_cl_first = nullptr;
   unsigned n_vox_total = 0, n_fit_total = 0, n_cl_total = 0;
   // F1 (hope_clusters_upon_plane): clusters as ranges of d_upon_xyz / d_upon_src, in output order
@@ -930,6 +932,7 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   ALLOC(rec, ClusterRec, std::max(n_cl, 1u));
   c->d_cid = cid;
   c->d_members = members;
+  c->d_fit_pt = fit_pt;
   c->d_cl_first = cl_first;
   pm = prof_mark(c);
   hipLaunchKernelGGL(k_point_clusters, dim3(gb), dim3(kBlock), 0, s, label, seg_flags, seg_scan, n_fit, n_cl, cid, mkey,
@@ -1012,6 +1015,7 @@ int run_pipeline(hope_ctx* c, const Src& src, size_t n_per_frame)
   c->d_knn = nullptr;
   c->d_cid = nullptr;
   c->d_members = nullptr;
+  c->d_fit_pt = nullptr;
   c->d_cl_first = nullptr;
   if ((unsigned long long)n_per_frame * (unsigned long long)F >= 0xffffffffull) {
     c->err = "input larger than 2^32-1 points per call is not supported";
@@ -2167,6 +2171,37 @@ HOPE_API int hope_get_cluster_indices(hope_ctx* c, int frame, int cluster, int32
   if (st != HOPE_OK) return st;
   for (int i = 0; i < r.size; ++i) idx[i] -= F.fit_start;
   return r.size;
+}
+
+// F2: the members of a cluster that can be vertices of the convex hull of its xy projection (hull.hpp)
+HOPE_API int hope_get_cluster_hull_candidates(hope_ctx* c, int frame, int cluster, int32_t* pos, int cap)
+{
+  ROUTE(c, frame, hope_get_cluster_hull_candidates(kid__, local__, cluster, pos, cap));
+  GET_FRAME(c, frame);
+  if (cluster < 0 || cluster >= F.n_clusters) return HOPE_E_RANGE;
+  if (cap < 0 || (cap > 0 && !pos)) return HOPE_E_INVALID;
+  const ClusterRec& r = c->h_rec[F.cl_start + cluster];
+  if (r.size <= 0) return 0;
+  if (!c->d_members || !c->d_fit_pt || !c->d_cl_first) {
+    c->err = "hope_get_cluster_hull_candidates: no cluster member lists on this ctx";
+    return HOPE_E_INVALID;
+  }
+  HIPCHK(hipSetDevice(c->cfg.device));
+  const ArenaScope scope(c->arena);  // (scratch of this export only: given back on return)
+  uint32_t *d_pos, *d_count;
+  ALLOC(d_pos, uint32_t, (size_t)r.size);
+  ALLOC(d_count, uint32_t, 1);
+  hipLaunchKernelGGL(k_hull_candidates, dim3(1), dim3(kHullBlock), 0, c->stream, c->d_members,
+                     c->d_cl_first + F.cl_start + cluster, (unsigned)r.size, c->d_fit_pt, d_pos, d_count);
+  uint32_t n = 0;
+  int st = copy_out(c, &n, d_count, sizeof(uint32_t));
+  if (st != HOPE_OK) return st;
+  const uint32_t take = std::min<uint32_t>(n, (uint32_t)cap);
+  if (take > 0) {
+    st = copy_out(c, pos, d_pos, sizeof(int32_t) * (size_t)take);
+    if (st != HOPE_OK) return st;
+  }
+  return (int)n;
 }
 
 HOPE_API int hope_get_max_plane(hope_ctx* c, int frame, hope_max_plane* out)

@@ -44,6 +44,16 @@ struct FrameArrays {
     out.width = (uint32_t)out.points.size(); out.height = 1; out.is_dense = true;
     return true;
   }
+  // F2: the few members of cluster c that can be hull vertices (reduced on the device), as indices into a cloud in
+  // which the cluster's points start at `offset`
+  bool hull_candidates(hope_ctx* ctx, int frame, int c, int offset, std::vector<int>& out) const
+  {
+    std::vector<int32_t> pos((size_t)clusters[c].size);
+    const int n = hope_get_cluster_hull_candidates(ctx, frame, c, pos.data(), (int)pos.size());
+    if (n < 0 || n > (int)pos.size()) return false;
+    for (int i = 0; i < n; ++i) out.push_back(offset + pos[i]);
+    return true;
+  }
 };
 
 }  // namespace
@@ -98,7 +108,9 @@ bool PlaneSegment::collect(int frame)
       plane_coeff_.push_back({cl.z_mean, cl.min_x, cl.min_y, cl.max_x, cl.max_y});    // :408-420
       if (cal_hull_) {                                                                // :376-378 (upstream hulls the empty rgb cloud)
         PointCloudMono hull;
-        plane_area_.push_back((float)computeHull(*pts, hull));
+        std::vector<int> cand;
+        if (!fa.hull_candidates(ctx_, frame, c, 0, cand)) return false;
+        plane_area_.push_back((float)computeHull(*pts, hull, nullptr, &cand));        // :391-406 on the device-reduced points
         PointCloud::Ptr hull_rgb(new PointCloud);
         for (const PointXYZ& p : hull.points) { PointXYZRGB q; q.x = p.x; q.y = p.y; q.z = p.z; hull_rgb->push_back(q); }
         plane_hull_.push_back(hull_rgb);
@@ -225,10 +237,14 @@ void PlaneSegmentRT::getHorizontalPlanes()
     if (!fa.load(ctx_, 0, c)) return;
     std::vector<int32_t> members((size_t)std::max(mp.n_members, 1));   // (every merged cluster: upstream has no limit)
     if (hope_get_max_plane_members(ctx_, 0, members.data(), mp.n_members) != mp.n_members) return;
-    for (int m = 0; m < mp.n_members; ++m)                          // combineCloud order, :943-955 / utilities.cpp:1717-1727
+    std::vector<int> cand;                                          // a vertex of the merged hull is one of its own cluster's hull
+    for (int m = 0; m < mp.n_members; ++m) {                        // combineCloud order, :943-955 / utilities.cpp:1717-1727
+      const int offset = (int)max_plane_cloud_->size();
       if (!fa.cluster_cloud(ctx_, 0, members[m], *max_plane_cloud_, true)) return;
+      if (!fa.hull_candidates(ctx_, 0, members[m], offset, cand)) return;
+    }
     max_plane_z_ = mp.z;                                            // :958
-    max_plane_area_ = computeHull(*max_plane_cloud_, *max_plane_contour_);   // :957
+    max_plane_area_ = computeHull(*max_plane_cloud_, *max_plane_contour_, nullptr, &cand);   // :957, on the device-reduced points
   }
   if (!max_plane_cloud_->empty())
     std::printf("Max plane z=%.3f detected in height range %.3f, %.3f\n", max_plane_z_, min_height_, max_height_);   // :983-989

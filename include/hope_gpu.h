@@ -176,6 +176,13 @@ HOPE_API int hope_get_clusters(hope_ctx* ctx, int frame, hope_cluster* out, int 
 /* seed_clusters_indices_[cluster].indices (ascending, into the fit cloud) */
 HOPE_API int hope_get_cluster_indices(hope_ctx* ctx, int frame, int cluster, int32_t* idx,
                                       int cap);
+/* F2, the device side of Utilities::computeHull (utilities.cpp:1531-1536, called plane_segment.cpp:957) and
+ * PlaneSegment::computeHull (plane_segment.cpp:391-406), which hand every point of a plane to pcl::ConvexHull:
+ * the positions (into the list hope_get_cluster_indices returns, ascending) of the members that are NOT strictly
+ * inside the octagon of the cluster's eight extreme points. Every vertex of the convex hull of the cluster's xy
+ * projection is among them, so the hull of these few points is the hull of the cluster. Returns their number
+ * (which may exceed cap; at most cap are written). */
+HOPE_API int hope_get_cluster_hull_candidates(hope_ctx* ctx, int frame, int cluster, int32_t* pos_out, int cap);
 /* PlaneSegmentRT::max_plane_* */
 HOPE_API int hope_get_max_plane(hope_ctx* ctx, int frame, hope_max_plane* out);
 /* every cluster whose points form max_plane_cloud_ (plane_segment.cpp:943-955: combineCloud puts the

@@ -1529,6 +1529,18 @@ ORACLE_API int hope_oracle_get_cluster_indices(hope_ctx* ctx, int frame, int clu
   return (int)v.size();
 }
 
+// F2: the reference hulls EVERY point of a plane (utilities.cpp:1531-1536, plane_segment.cpp:391-406), so here
+// every member is a candidate; the device library's pre-filter has no counterpart in the reference.
+ORACLE_API int hope_oracle_get_cluster_hull_candidates(hope_ctx* ctx, int frame, int cluster, int32_t* pos, int cap)
+{
+  GET_FRAME(ctx, frame);
+  if (cluster < 0 || cluster >= (int)f.clusters.size()) return HOPE_E_RANGE;
+  if (cap < 0 || (cap > 0 && !pos)) return HOPE_E_INVALID;
+  const int n = (int)f.clusters[cluster].indices.size();
+  for (int i = 0; i < n && i < cap; ++i) pos[i] = i;
+  return n;
+}
+
 ORACLE_API int hope_oracle_get_max_plane(hope_ctx* ctx, int frame, hope_max_plane* out)
 {
   GET_FRAME(ctx, frame);

@@ -721,6 +721,55 @@ def test_full_size_multilevel_scene(hip_lib, oracle_lib):
 
 
 @pytest.mark.gpu
+def test_hull_candidates_hold_every_hull_vertex(hip_lib, oracle_lib, tum_example):
+    """F2: hope_get_cluster_hull_candidates keeps the members outside the octagon of the cluster's extreme points.
+    Every vertex qhull (scipy; the library behind pcl::ConvexHull) finds on ALL points of a plane must be among
+    them, the hull of the candidates alone has the same area, and on large planes they are a small fraction."""
+    from scipy.spatial import ConvexHull
+    from hope_amd import synth
+    depth, t, q = tum_example
+    g = HopeContext(hip_lib)
+    g.set_pose(t, q)
+    g.segment_depth(depth)
+    cases = [(g, 0)]
+    sd, st_, sq = synth_frames(3, first=5)
+    g2 = HopeContext(hip_lib)
+    g2.set_frame_poses(st_, sq)
+    g2.segment_depth(sd)
+    cases += [(g2, f) for f in range(3)]
+    g3 = HopeContext(hip_lib)
+    g3.segment_cloud(synth.make_multilevel_cloud(400000, first_index=0, device="cpu").numpy())
+    cases.append((g3, 0))
+    checked = big = 0
+    for c, f in cases:
+        vox, fit, cl = c.downsampled(f), c.fit_indices(f), c.clusters(f)
+        for ci in range(len(cl)):
+            size = int(cl["size"][ci])
+            if not cl["pass"][ci] or size < 3:
+                continue
+            pts = vox[fit[c.cluster_indices(f, ci, size)]][:, :2].astype(np.float64)
+            cand = c.cluster_hull_candidates(f, ci, size)
+            assert np.all(np.diff(cand) > 0) and cand[0] >= 0 and cand[-1] < size
+            if len(np.unique(pts, axis=0)) < 3 or np.linalg.matrix_rank(pts - pts[0]) < 2:
+                continue
+            full = ConvexHull(pts)
+            assert set(full.vertices.tolist()) <= set(cand.tolist())
+            sub = ConvexHull(pts[cand])
+            assert abs(sub.volume - full.volume) <= 1e-12 * full.volume        # (2-D: volume is the area)
+            checked += 1
+            if size >= 4000:
+                big += 1
+                assert len(cand) < size // 3, (size, len(cand))
+    assert checked >= 10 and big >= 1
+    # the oracle side of the same entry point: the reference hulls every point
+    o = HopeContext(oracle_lib)
+    o.set_pose(t, q)
+    o.segment_depth(depth)
+    ocl = o.clusters(0)
+    ci = int(np.argmax(ocl["size"]))
+    assert np.array_equal(o.cluster_hull_candidates(0, ci, int(ocl["size"][ci])), np.arange(int(ocl["size"][ci])))
+
+
 def test_hope_node_and_rt_adapter_on_the_device(oracle_lib, tum_example, tmp_path):
     """The C++ host layer linked on libhope_hip.so: `hope_node` (single pair, list mode) and the PlaneSegmentRT
     driver give the records the oracle gives through the same C ABI."""
