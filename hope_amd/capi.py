@@ -73,7 +73,7 @@ ABI_SYMBOLS = [
     "get_knn", "get_labels", "get_clusters", "get_cluster_indices", "get_cluster_hull_candidates", "get_max_plane", "get_max_plane_members",
     "last_timing", "grid_from_bbox", "shard_bbox", "shard_z_histogram", "shard_route",
     "downsample_cloud_bbox", "segment_downsampled", "segment_downsampled_staged",
-    "get_normals_rows", "get_knn_rows", "get_downsampled_to",
+    "get_normals_rows", "get_knn_rows", "get_downsampled_to", "count_band_crossings",
     "clusters_upon_plane", "get_upon_cluster_sizes", "get_upon_cluster",
 ]
 
@@ -128,6 +128,7 @@ class HopeLib:
             "get_downsampled_to": (C.c_int, [vp, i32, vp, i32]),
             "get_normals_rows": (C.c_int, [vp, i32, C.c_int64, C.c_int64, vp, i32]),
             "get_knn_rows": (C.c_int, [vp, i32, C.c_int64, C.c_int64, vp, i32]),
+            "count_band_crossings": (C.c_int, [vp, i32, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),
             "segment_downsampled_staged": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, i32, vp, C.c_int64, C.c_int64,
                                                      C.c_int64, vp, vp, i32]),
             "clusters_upon_plane": (C.c_int, [vp, i32, vp, i32, C.c_float, i32, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
@@ -373,6 +374,13 @@ class HopeContext:
         self._check(self.lib.fn["get_knn_rows"](self._h, frame, int(first), int(count), out.ctypes.data, 0),
                     "get_knn_rows")
         return out
+
+    def count_band_crossings(self, fit_first, fit_count, frame=0):
+        """Valid edges (|dz| < th_z) from the fit points [fit_first, fit_first + fit_count) to fit points outside."""
+        n = C.c_int64(0)
+        self._check(self.lib.fn["count_band_crossings"](self._h, frame, fit_first, fit_count, C.byref(n)),
+                    "count_band_crossings")
+        return int(n.value)
 
     def normals(self, frame=0):
         n = self.counts(frame).n_vox

@@ -741,6 +741,7 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   ALLOC(fit_nrm, float4, std::max(n_fit, 1u));
   ALLOC(fit_frame, int, std::max(n_fit, 1u));
   c->d_fit_idx = fit_idx;
+  c->d_fit_pt = fit_pt;
   pm = prof_mark(c);
   hipLaunchKernelGGL(k_fit_scatter, dim3(nblk(n_vox)), dim3(kBlock), 0, s, flags, fscan, n_vox, d_vox, d_normals,
                      d_vox_frame, fit_rank, fit_idx, fit_pt, fit_nrm, fit_frame);
@@ -932,7 +933,6 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   ALLOC(rec, ClusterRec, std::max(n_cl, 1u));
   c->d_cid = cid;
   c->d_members = members;
-  c->d_fit_pt = fit_pt;
   c->d_cl_first = cl_first;
   pm = prof_mark(c);
   hipLaunchKernelGGL(k_point_clusters, dim3(gb), dim3(kBlock), 0, s, label, seg_flags, seg_scan, n_fit, n_cl, cid, mkey,
@@ -2171,6 +2171,54 @@ HOPE_API int hope_get_cluster_indices(hope_ctx* c, int frame, int cluster, int32
   if (st != HOPE_OK) return st;
   for (int i = 0; i < r.size; ++i) idx[i] -= F.fit_start;
   return r.size;
+}
+
+// rows [fit_first, fit_first + fit_count) of the k-NN table: edges ZGrowing would follow (|dz| < th_z, validatePoint,
+// z_growing.cpp:335-364) that end outside that range of fit points
+__global__ void k_count_band_crossings(const int* knn, const float4* fit_pt, int K, float th_z, unsigned lo, unsigned hi,
+                                       unsigned long long* n_cross)
+{
+  const unsigned g = lo + blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned mine = 0u;
+  if (g < hi) {
+    const float zg = fit_pt[g].z;
+    for (int j = 0; j < K; ++j) {
+      const int v = knn[(size_t)g * K + j];
+      if (v < 0 || ((unsigned)v >= lo && (unsigned)v < hi)) continue;
+      if (fabsf(zg - fit_pt[v].z) < th_z) ++mine;
+    }
+  }
+  for (int o = kWave / 2; o > 0; o >>= 1) mine += (unsigned)__shfl_down((int)mine, o);
+  if ((threadIdx.x & (kWave - 1)) == 0 && mine) atomicAdd(n_cross, (unsigned long long)mine);
+}
+
+HOPE_API int hope_count_band_crossings(hope_ctx* c, int frame, int64_t fit_first, int64_t fit_count, int64_t* n_cross)
+{
+  ROUTE(c, frame, hope_count_band_crossings(kid__, local__, fit_first, fit_count, n_cross));
+  GET_FRAME(c, frame);
+  if (!n_cross || fit_first < 0 || fit_count < 0 || fit_first + fit_count > F.n_fit) return HOPE_E_INVALID;
+  *n_cross = 0;
+  if (fit_count == 0) return HOPE_OK;
+  if (!c->d_knn || !c->d_fit_pt) {
+    c->err = "hope_count_band_crossings: the ctx holds no k-NN rows";
+    return HOPE_E_INVALID;
+  }
+  if (c->h_fi.size() != 1) {
+    c->err = "hope_count_band_crossings: single-cloud calls only";
+    return HOPE_E_INVALID;
+  }
+  HIPCHK(hipSetDevice(c->cfg.device));
+  const ArenaScope scope(c->arena);
+  unsigned long long* d_n;
+  ALLOC(d_n, unsigned long long, 1);
+  HIPCHK(hipMemsetAsync(d_n, 0, sizeof(unsigned long long), c->stream));
+  hipLaunchKernelGGL(k_count_band_crossings, dim3(nblk((size_t)fit_count)), dim3(kBlock), 0, c->stream, c->d_knn,
+                     c->d_fit_pt, c->cfg.knn, c->cfg.th_z, (unsigned)fit_first, (unsigned)(fit_first + fit_count), d_n);
+  unsigned long long n = 0;
+  const int st = copy_out(c, &n, d_n, sizeof(n));
+  if (st != HOPE_OK) return st;
+  *n_cross = (int64_t)n;
+  return HOPE_OK;
 }
 
 // F2: the members of a cluster that can be vertices of the convex hull of its xy projection (hull.hpp)

@@ -17,7 +17,11 @@
 #include <vector>
 
 #include "formats.hpp"
+#include "plane_id.hpp"
 #include "plane_segment.hpp"
+#ifdef HOPE_NODE_MULTI_GPU
+#include "rccl_comm.hpp"
+#endif
 
 using namespace hope;
 
@@ -146,6 +150,47 @@ int main(int argc, char** argv)
       } else if (cloud_type == "ply") {
         if (!readPly(path_cloud, *src_cloud, err)) { std::cerr << "Couldn't read ply file. (" << err << ")" << std::endl; return -1; }
       } else { std::cerr << "Unrecognized file format." << std::endl; return -1; }
+#ifdef HOPE_NODE_MULTI_GPU
+      // HOPE_NODE_GPUS=N: the cloud in N contiguous ranges, one thread, ctx and RCCL communicator per GPU
+      // (rccl_comm.cpp / multi_gpu.cpp; exchanges as in DESIGN.md section 7).  No counterpart upstream.
+      if (const char* g = std::getenv("HOPE_NODE_GPUS")) {
+        const int n_gpus = std::atoi(g);
+        hope_config cfg;
+        hope_config_default(&cfg);
+        cfg.th_xy = xy_resolution; cfg.th_z = z_resolution; cfg.mode = HOPE_MODE_OFFLINE;
+        std::vector<float> xyz(3 * src_cloud->size());
+        for (size_t i = 0; i < src_cloud->size(); ++i) {
+          xyz[3 * i] = src_cloud->points[i].x; xyz[3 * i + 1] = src_cloud->points[i].y; xyz[3 * i + 2] = src_cloud->points[i].z;
+        }
+        MultiResult m;
+        const int st = run_cloud_on_gpus(n_gpus, cfg, xyz.data(), src_cloud->size(), 0, nullptr, nullptr, m, err);   // POINT_CLOUD: no filter, no pose (:118-120)
+        if (st < 0) { std::cerr << "HoPE multi-GPU: " << err << std::endl; return 1; }
+        std::vector<std::vector<float>> coeff;
+        std::vector<int> points;
+        for (const hope_cluster& k : m.clusters)
+          if (k.pass == 1) { coeff.push_back({k.z_mean, k.min_x, k.min_y, k.max_x, k.max_y}); points.push_back(k.size); }
+        PlaneIdTracker ids;
+        ids.setID(coeff);
+        std::printf("[%s] %d GPUs (%s)  raw %lld  down-sampled %lld  normal-fit %lld  clusters %zu  planes %zu\n", path_cloud.c_str(), n_gpus,
+                    m.path.c_str(), (long long)m.n_raw_total, (long long)m.n_vox, (long long)m.n_fit, m.clusters.size(), coeff.size());
+        for (size_t i = 0; i < coeff.size(); ++i)
+          std::printf("  plane id %3d  z %.4f  x [%.3f, %.3f]  y [%.3f, %.3f]  points %d\n", ids.global_id_temp_[i], coeff[i][0], coeff[i][1],
+                      coeff[i][3], coeff[i][2], coeff[i][4], points[i]);
+        if (dump) {
+          *dump << "{\"frame\": \"" << path_cloud << "\", \"gpus\": " << n_gpus << ", \"path\": \"" << m.path << "\", \"n_raw\": " << m.n_raw_total
+                << ", \"n_vox\": " << m.n_vox << ", \"n_fit\": " << m.n_fit << ", \"n_clusters\": " << m.clusters.size() << ", \"status\": " << st
+                << ", \"planes\": [";
+          char buf[256];
+          for (size_t i = 0; i < coeff.size(); ++i) {
+            std::snprintf(buf, sizeof buf, "%s{\"id\": %d, \"coeff\": [%.9g, %.9g, %.9g, %.9g, %.9g], \"points\": %d, \"hull\": 0, \"area\": 0}",
+                          i ? ", " : "", ids.global_id_temp_[i], coeff[i][0], coeff[i][1], coeff[i][2], coeff[i][3], coeff[i][4], points[i]);
+            *dump << buf;
+          }
+          *dump << "]}" << std::endl;
+        }
+        return 0;
+      }
+#endif
       hope.setQ(qx, qy, qz, qw);
       hope.getHorizontalPlanes(src_cloud);
       if (hope.last_status() < 0) return 1;

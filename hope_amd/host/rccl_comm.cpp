@@ -1,0 +1,142 @@
+// RCCL backend of multi_gpu.hpp (see rccl_comm.hpp).  Host C++ against the HIP runtime API and RCCL; no kernels here.
+#include "rccl_comm.hpp"
+
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <stdexcept>
+#include <thread>
+
+namespace hope {
+namespace {
+
+#define HIP_OK(x)                                                                              \
+  do {                                                                                         \
+    const hipError_t e__ = (x);                                                                \
+    if (e__ != hipSuccess) throw std::runtime_error(std::string(#x ": ") + hipGetErrorString(e__)); \
+  } while (0)
+#define NCCL_OK(x)                                                                               \
+  do {                                                                                           \
+    const ncclResult_t r__ = (x);                                                                \
+    if (r__ != ncclSuccess) throw std::runtime_error(std::string(#x ": ") + ncclGetErrorString(r__)); \
+  } while (0)
+
+class RcclComm : public Comm {
+ public:
+  RcclComm(ncclComm_t comm, int rank, int world, int device) : comm_(comm), rank_(rank), world_(world), device_(device)
+  {
+    HIP_OK(hipSetDevice(device_));
+    HIP_OK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  }
+  ~RcclComm() override { (void)hipSetDevice(device_); (void)hipStreamDestroy(stream_); }
+  int rank() const override { return rank_; }
+  int world() const override { return world_; }
+  int on_device() const override { return 1; }
+  void* alloc(size_t bytes) override
+  {
+    void* p = nullptr;
+    HIP_OK(hipSetDevice(device_));
+    HIP_OK(hipMalloc(&p, bytes ? bytes : 1));
+    return p;
+  }
+  void release(void* p) override { (void)hipSetDevice(device_); (void)hipFree(p); }
+  void put(void* d, const void* s, size_t b) override { if (b) HIP_OK(hipMemcpy(d, s, b, hipMemcpyHostToDevice)); }
+  void get(void* d, const void* s, size_t b) override { if (b) HIP_OK(hipMemcpy(d, s, b, hipMemcpyDeviceToHost)); }
+  void copy(void* d, const void* s, size_t b) override { if (b) HIP_OK(hipMemcpy(d, s, b, hipMemcpyDeviceToDevice)); }
+  void fill_ff(void* d, size_t b) override { if (b) { HIP_OK(hipMemset(d, 0xff, b)); HIP_OK(hipDeviceSynchronize()); } }
+  void all_reduce_max_f32(float* buf, size_t n) override
+  {
+    NCCL_OK(ncclAllReduce(buf, buf, n, ncclFloat, ncclMax, comm_, stream_));
+    HIP_OK(hipStreamSynchronize(stream_));
+  }
+  void all_reduce_sum_i64(int64_t* buf, size_t n) override
+  {
+    NCCL_OK(ncclAllReduce(buf, buf, n, ncclInt64, ncclSum, comm_, stream_));
+    HIP_OK(hipStreamSynchronize(stream_));
+  }
+  void all_gather_v(const void* send, void* recv, const std::vector<size_t>& bytes) override
+  {
+    // pieces of different sizes: one broadcast per piece, grouped (xGMI is point to point: each piece travels
+    // from its owner to the seven others, which is what a ring all-gather moves as well)
+    NCCL_OK(ncclGroupStart());
+    size_t at = 0;
+    for (int r = 0; r < world_; ++r) {
+      if (bytes[r]) NCCL_OK(ncclBroadcast(send, static_cast<char*>(recv) + at, bytes[r], ncclChar, r, comm_, stream_));
+      at += bytes[r];
+    }
+    NCCL_OK(ncclGroupEnd());
+    HIP_OK(hipStreamSynchronize(stream_));
+  }
+  void all_to_all_v(const float* send, const std::vector<int64_t>& sc, float* recv, const std::vector<int64_t>& rc) override
+  {
+    NCCL_OK(ncclGroupStart());
+    size_t so = 0, ro = 0;
+    for (int r = 0; r < world_; ++r) {
+      if (sc[r]) NCCL_OK(ncclSend(send + so, (size_t)sc[r], ncclFloat, r, comm_, stream_));
+      if (rc[r]) NCCL_OK(ncclRecv(recv + ro, (size_t)rc[r], ncclFloat, r, comm_, stream_));
+      so += (size_t)sc[r];
+      ro += (size_t)rc[r];
+    }
+    NCCL_OK(ncclGroupEnd());
+    HIP_OK(hipStreamSynchronize(stream_));
+  }
+
+ private:
+  ncclComm_t comm_;
+  int rank_, world_, device_;
+  hipStream_t stream_ = nullptr;
+};
+
+}  // namespace
+
+int run_cloud_on_gpus(int n_gpus, const hope_config& cfg, const float* xyz_host, size_t n, int apply,
+                      const float* t_xyz, const float* q_xyzw, MultiResult& out, std::string& err)
+{
+  int have = 0;
+  if (hipGetDeviceCount(&have) != hipSuccess || have < n_gpus || n_gpus < 1) {
+    err = "run_cloud_on_gpus: " + std::to_string(n_gpus) + " GPUs asked for, " + std::to_string(have) + " visible";
+    return HOPE_E_INVALID;
+  }
+  std::vector<ncclComm_t> comms((size_t)n_gpus);
+  std::vector<int> devs((size_t)n_gpus);
+  for (int r = 0; r < n_gpus; ++r) devs[r] = r;
+  const ncclResult_t nr = ncclCommInitAll(comms.data(), n_gpus, devs.data());
+  if (nr != ncclSuccess) {
+    err = std::string("ncclCommInitAll: ") + ncclGetErrorString(nr);
+    return HOPE_E_INVALID;
+  }
+  std::vector<int> status((size_t)n_gpus, 0);
+  std::vector<std::string> errs((size_t)n_gpus);
+  std::vector<MultiResult> results((size_t)n_gpus);
+  std::vector<std::thread> threads;
+  for (int r = 0; r < n_gpus; ++r)
+    threads.emplace_back([&, r] {
+      hope_ctx* ctx = nullptr;
+      try {
+        hope_config c = cfg;
+        c.device = r;
+        if (hope_create(&c, &ctx) != HOPE_OK) throw std::runtime_error("hope_create failed on device " + std::to_string(r));
+        if (t_xyz && q_xyzw) hope_set_pose(ctx, t_xyz, q_xyzw);
+        RcclComm comm(comms[r], r, n_gpus, r);
+        const size_t lo = n * (size_t)r / (size_t)n_gpus, hi = n * (size_t)(r + 1) / (size_t)n_gpus;
+        status[r] = segment_cloud_multi(ctx, comm, xyz_host + 3 * lo, hi - lo, apply, c, results[r], errs[r]);
+      } catch (const std::exception& e) {
+        // (a rank that fails before a collective leaves the others waiting in it: RCCL has no timeout here, so the
+        //  errors that can be foreseen -- arguments, device count -- are checked before the threads start)
+        status[r] = HOPE_E_INVALID;
+        errs[r] = e.what();
+      }
+      if (ctx) hope_destroy(ctx);
+    });
+  for (std::thread& t : threads) t.join();
+  for (int r = 0; r < n_gpus; ++r) ncclCommDestroy(comms[r]);
+  for (int r = 0; r < n_gpus; ++r)
+    if (status[r] < 0) {
+      err = "rank " + std::to_string(r) + ": " + errs[r];
+      return status[r];
+    }
+  out = std::move(results[0]);
+  return status[0];
+}
+
+}  // namespace hope

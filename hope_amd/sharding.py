@@ -254,14 +254,7 @@ def segment_cloud_sharded(ctx, xyz_local, dist, apply_filter_transform=False, al
     #    on the k-NN rows themselves (every rank its own rows: an edge into a band is an edge out of another).
     crossing = torch.zeros(1, dtype=torch.int32, device=dev)
     if hi > lo and allow_bands:
-        fit_t = torch.from_numpy(np.ascontiguousarray(fit_idx, dtype=np.int64)).to(dev)
-        z = vox_all[fit_t, 2]
-        nb = own_k.to(torch.int64)
-        valid = nb >= 0
-        foreign = valid & ((nb < lo) | (nb >= hi))
-        dz = (z[lo:hi, None] - z[nb.clamp(min=0)]).abs()
-        th_z = torch.tensor(ctx.cfg.th_z, dtype=torch.float32, device=dev)
-        crossing[0] = int(bool((foreign & (dz < th_z)).any().item()))
+        crossing[0] = int(ctx.count_band_crossings(lo, hi - lo) > 0)
     if not allow_bands:
         crossing[0] = 1
     dist.all_reduce(crossing, op=dist.ReduceOp.MAX)

@@ -283,6 +283,14 @@ HOPE_API int hope_get_normals_rows(hope_ctx* ctx, int frame, int64_t first, int6
                                    float* nxyzc, int out_on_device);
 HOPE_API int hope_get_knn_rows(hope_ctx* ctx, int frame, int64_t first, int64_t count,
                                int32_t* nbr, int out_on_device);
+/* After call b of the staged form: the number of edges ZGrowing would follow (neighbour j of fit point i with
+ * |z_i - z_j| < th_z: validatePoint, z_growing.cpp:335-364) from the fit points [fit_first, fit_first + fit_count)
+ * -- whose k-NN rows the ctx holds -- to fit points outside that range.  Zero on every rank means the z bands
+ * are independent extraction problems: call c may then be given the own rows only (all others -1), and the
+ * records of the own band are exactly those of the whole cloud (seed ranks are global).  No counterpart in the
+ * reference. */
+HOPE_API int hope_count_band_crossings(hope_ctx* ctx, int frame, int64_t fit_first, int64_t fit_count,
+                                       int64_t* n_cross);
 HOPE_API int hope_segment_downsampled_staged(hope_ctx* ctx, const void* vox_xyz, size_t n_vox,
                                              size_t stride_bytes, int on_device,
                                              const float bbox_min_max[6], int64_t n_raw_total,

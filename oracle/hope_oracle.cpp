@@ -1476,6 +1476,26 @@ ORACLE_API int hope_oracle_get_knn_rows(hope_ctx* ctx, int frame, int64_t first,
   return HOPE_OK;
 }
 
+// Edges growRegion would follow (validatePoint, z_growing.cpp:335-364: |dz| < th_z) from the fit points
+// [fit_first, fit_first + fit_count) to fit points outside that range (multi-GPU: are the z bands independent?)
+ORACLE_API int hope_oracle_count_band_crossings(hope_ctx* ctx, int frame, int64_t fit_first, int64_t fit_count,
+                                                int64_t* n_cross)
+{
+  GET_FRAME(ctx, frame);
+  const int64_t K = ctx->cfg.knn, n_fit = (int64_t)f.fz.size();
+  if (!n_cross || fit_first < 0 || fit_count < 0 || fit_first + fit_count > n_fit) return HOPE_E_INVALID;
+  *n_cross = 0;
+  if (fit_count == 0) return HOPE_OK;
+  if ((int64_t)f.knn.size() < (fit_first + fit_count) * K) return HOPE_E_INVALID;
+  for (int64_t g = fit_first; g < fit_first + fit_count; ++g)
+    for (int64_t j = 0; j < K; ++j) {
+      const int v = f.knn[(size_t)(g * K + j)];
+      if (v < 0 || (v >= fit_first && v < fit_first + fit_count)) continue;
+      if (std::fabs(f.fz[g] - f.fz[v]) < ctx->cfg.th_z) ++*n_cross;
+    }
+  return HOPE_OK;
+}
+
 ORACLE_API int hope_oracle_get_fit_indices(hope_ctx* ctx, int frame, int32_t* idx)
 {
   GET_FRAME(ctx, frame);

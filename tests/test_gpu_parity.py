@@ -816,3 +816,26 @@ def test_hope_node_and_rt_adapter_on_the_device(oracle_lib, tum_example, tmp_pat
         assert out[0].returncode == 0 and out[1].returncode == 0, (out[0].stderr, out[1].stderr)
         assert json.loads(out[0].stdout.splitlines()[-1]) == json.loads(out[1].stdout.splitlines()[-1])
         assert json.loads(out[0].stdout.splitlines()[-1])["points"] > 0
+
+
+def test_hope_node_over_rccl(oracle_lib, tmp_path, monkeypatch):
+    """`hope_node <file> ply` with HOPE_NODE_GPUS=1: the C++ multi-GPU host (hope_amd/host/multi_gpu.cpp over
+    rccl_comm.cpp: ncclCommInitAll, all-reduces, the all-to-all of routed points, the all-gather of the down-sampled
+    cloud -- all real RCCL calls, one rank being what a one-GPU box can hold; 2 and 3 ranks of the same orchestration
+    run on threads in tests/test_multi_host_cpu.py).  Records == the oracle's on the whole cloud."""
+    from test_host_cpu import check_record, run_node
+    from test_sharding_cpu import _layer_cloud
+    node = os.path.join(ROOT, "hope_amd", "host", "hope_node")
+    xyz = _layer_cloud()
+    p = tmp_path / "layers.ply"
+    p.write_bytes(("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+                   "end_header\n" % len(xyz)).encode() + xyz.tobytes())
+    monkeypatch.setenv("HOPE_NODE_GPUS", "1")
+    r, recs = run_node(node, [p, "ply"], tmp_path, hull=False)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert recs[0]["gpus"] == 1 and recs[0]["path"] == "one rank"
+    c = HopeContext(oracle_lib)
+    c.segment_cloud(xyz, apply_filter_transform=False)
+    planes = [k for k in c.clusters(0) if k["pass"] == 1]
+    assert len(planes) >= 4
+    check_record(recs[0], c.counts(0), planes)
