@@ -191,6 +191,7 @@ struct hope_ctx {
   int pixel_sort = 0;         // test knob: depth frames through the per-pixel sort (the cloud path's voxel stage)
   int col_sort_z = 0;         // test knob HOPE_DEBUG_COLSORT_Z=1: z cell bits in the column sort key even for VoxelGrid output
   int seg_sort = 1;           // per-frame segmented sort of the group records (HOPE_DEBUG_SEGSORT=0: device-wide sort)
+  int tile_side = 0;          // neighbour tiles: 0 = chosen per call from the points per super tile; HOPE_DEBUG_TILE_SIDE=16|32 forces
   int voxel_rank = 1;         // depth batches: voxels ranked by an LDS bitmap per frame instead of sorting the group
                               // records (HOPE_DEBUG_VOXEL_RANK=0, or any knob that asks for a sort: the sorting path)
   uint32_t* d_grp_cnt = nullptr;  // depth path: groups per chunk, then its exclusive scan
@@ -699,16 +700,30 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   ALLOC(d_normals, float4, n_vox);
   c->d_normals = d_normals;
   pm = prof_mark(c);
-  const dim3 tile_grid(std::max(1u, c->h_glob->max_tiles), F);
+  // 32x32-column super tiles when a super tile + halo usually fits in LDS (the bench's depth frames: ~700 points per
+  // super tile, normals 2.06 -> 1.96 ms, k-NN 1.87 -> 1.76 ms), 16x16 tiles for dense clouds, where a super tile
+  // would only be four tiles run one after the other by a quarter of the workgroups (config 4, 2800 points per
+  // super tile: normals 12.2 instead of 6.3 ms)
+  const unsigned sum_tiles = std::max(1u, c->h_glob->sum_tiles);
+  const auto tile_side = [&](size_t points) { return points <= (size_t)kTileCap * 2 / 3 * sum_tiles ? kSuper : kTile; };
+  const auto tile_grid_of = [&](int side) {
+    return dim3(std::max(1u, side == kSuper ? c->h_glob->max_tiles : c->h_glob->max_tiles16), F);
+  };
+  const int side_n = c->tile_side ? c->tile_side : tile_side(n_vox);
+  const dim3 tile_grid = tile_grid_of(side_n);
   if (c->inj_normals) {
     HIPCHK(hipMemcpyAsync(d_normals, c->inj_normals, sizeof(float4) * (size_t)n_vox,
                           c->inj_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
-  } else if (c->normals_cap_small) {
-    hipLaunchKernelGGL((k_normals_tile<2>), tile_grid, dim3(kBlock), 0, s, spt, col_first, c->d_fi, c->inv_xy,
-                       c->inv_z, c->radius, c->r2, c->ring, c->own_lo, c->own_hi, d_normals, c->ablate % 10);
   } else {
-    hipLaunchKernelGGL((k_normals_tile<kNbCap>), tile_grid, dim3(kBlock), 0, s, spt, col_first, c->d_fi, c->inv_xy,
-                       c->inv_z, c->radius, c->r2, c->ring, c->own_lo, c->own_hi, d_normals, c->ablate % 10);
+#define HOPE_NORMALS(CAP, SIDE)                                                                                       \
+  hipLaunchKernelGGL((k_normals_tile<CAP, SIDE>), tile_grid, dim3(kBlock), 0, s, spt, col_first, c->d_fi, c->inv_xy, \
+                     c->inv_z, c->radius, c->r2, c->ring, c->own_lo, c->own_hi, d_normals, c->ablate % 10)
+    if (c->normals_cap_small) {
+      if (side_n == kSuper) HOPE_NORMALS(2, kSuper); else HOPE_NORMALS(2, kTile);
+    } else {
+      if (side_n == kSuper) HOPE_NORMALS(kNbCap, kSuper); else HOPE_NORMALS(kNbCap, kTile);
+    }
+#undef HOPE_NORMALS
   }
   prof_close(c, ST_NORMALS, pm, (16.0 + 16.0) * n_vox);
   if (c->stop_stage == 1) return HOPE_OK;
@@ -777,14 +792,18 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   if (c->inj_knn) {
     HIPCHK(hipMemcpyAsync(knn, c->inj_knn, sizeof(int) * (size_t)n_fit * K,
                           c->inj_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
-  } else if (K <= 8) {
-    hipLaunchKernelGGL((k_knn_tile<8>), tile_grid, dim3(kBlock), 0, s, spt_fit, col_first_fit, nullptr, c->d_fi,
-                       c->inv_xy, c->inv_z, c->cfg.th_xy, K, fit_idx, c->own_lo, c->own_hi, knn, todo,
-                       &c->d_glob->n_todo, (c->ablate / 10) % 10);
   } else {
-    hipLaunchKernelGGL((k_knn_tile<kMaxKnn>), tile_grid, dim3(kBlock), 0, s, spt_fit, col_first_fit, nullptr, c->d_fi,
-                       c->inv_xy, c->inv_z, c->cfg.th_xy, K, fit_idx, c->own_lo, c->own_hi, knn, todo,
-                       &c->d_glob->n_todo, (c->ablate / 10) % 10);
+    const int side_k = c->tile_side ? c->tile_side : tile_side(n_fit);
+#define HOPE_KNN(KL, SIDE)                                                                                              \
+  hipLaunchKernelGGL((k_knn_tile<KL, SIDE>), tile_grid_of(SIDE), dim3(kBlock), 0, s, spt_fit, col_first_fit, nullptr,   \
+                     c->d_fi, c->inv_xy, c->inv_z, c->cfg.th_xy, K, fit_idx, c->own_lo, c->own_hi, knn, todo,          \
+                     &c->d_glob->n_todo, (c->ablate / 10) % 10)
+    if (K <= 8) {
+      if (side_k == kSuper) HOPE_KNN(8, kSuper); else HOPE_KNN(8, kTile);
+    } else {
+      if (side_k == kSuper) HOPE_KNN(kMaxKnn, kSuper); else HOPE_KNN(kMaxKnn, kTile);
+    }
+#undef HOPE_KNN
   }
   prof_close(c, ST_KNN, pm, (16.0 + 4.0 * K) * (double)n_fit);
   {
@@ -1220,6 +1239,8 @@ HOPE_API int hope_create(const hope_config* cfg, hope_ctx** out)
   if (knob && std::atoi(knob) >= 1) c->sub_min_frames = std::atoi(knob);
   knob = std::getenv("HOPE_DEBUG_SEGSORT");
   c->seg_sort = (knob && knob[0] == '0') ? 0 : 1;
+  knob = std::getenv("HOPE_DEBUG_TILE_SIDE");
+  if (knob) c->tile_side = std::atoi(knob) == kSuper ? kSuper : (std::atoi(knob) == kTile ? kTile : 0);
   knob = std::getenv("HOPE_DEBUG_VOXEL_RANK");
   c->voxel_rank = (knob && knob[0] == '0') ? 0 : c->seg_sort;
   *out = c;

@@ -52,6 +52,8 @@ struct Globals {  // scalars produced on device, read back at the sync points
   unsigned int pad;
   unsigned int n_groups;  // depth path: number of (chunk, voxel) group records
   unsigned int max_tiles; // largest per-frame count of 32x32-column super tiles (neighbours.hpp)
+  unsigned int max_tiles16;  // ... of 16x16-column tiles
+  unsigned int sum_tiles;    // super tiles of all frames (the host picks the tile side from the points per super tile)
   unsigned int total_ccols;  // entries of the coarse column table
   unsigned int n_todo;       // k-NN queries left over by the tile pass
   unsigned int max_fit;      // largest per-frame count of fit points
@@ -205,7 +207,7 @@ __global__ void __launch_bounds__(1024) k_frame_grid(FrameInfo* fi, int n_frames
   __shared__ unsigned s_scan[1024];
   __shared__ unsigned long long s_max_cells;
   __shared__ unsigned long long s_all_cols;
-  __shared__ unsigned s_max_dz, s_any_over, s_carry, s_carry2, s_max_tiles;
+  __shared__ unsigned s_max_dz, s_any_over, s_carry, s_carry2, s_max_tiles, s_max_tiles16, s_sum_tiles;
   const int tid = threadIdx.x;
   if (tid == 0) {
     s_all_cols = 0;
@@ -215,6 +217,8 @@ __global__ void __launch_bounds__(1024) k_frame_grid(FrameInfo* fi, int n_frames
     s_carry = 0;
     s_carry2 = 0;
     s_max_tiles = 0;
+    s_max_tiles16 = 0;
+    s_sum_tiles = 0;
   }
   __syncthreads();
   for (int base = 0; base < n_frames; base += 1024) {
@@ -272,7 +276,10 @@ __global__ void __launch_bounds__(1024) k_frame_grid(FrameInfo* fi, int n_frames
           atomicMax(&s_max_dz, (unsigned)div_b[2]);
           ncols = (unsigned)(div_b[0] * div_b[1]) + 1u;
           nccols = (unsigned)(((div_b[0] + kCoarse - 1) / kCoarse) * ((div_b[1] + kCoarse - 1) / kCoarse)) + 1u;
-          atomicMax(&s_max_tiles, (unsigned)(((div_b[0] + 31) / 32) * ((div_b[1] + 31) / 32)));  // (neighbours.hpp: kSuper)
+          const unsigned t32 = (unsigned)(((div_b[0] + 31) / 32) * ((div_b[1] + 31) / 32));  // (neighbours.hpp: kSuper)
+          atomicMax(&s_max_tiles, t32);
+          atomicAdd(&s_sum_tiles, t32);
+          atomicMax(&s_max_tiles16, (unsigned)(((div_b[0] + 15) / 16) * ((div_b[1] + 15) / 16)));  // (kTile)
         }
       }
       for (int d = 0; d < 3; ++d) {
@@ -319,6 +326,8 @@ __global__ void __launch_bounds__(1024) k_frame_grid(FrameInfo* fi, int n_frames
     g->max_div_z = s_max_dz;
     g->any_overflow = s_any_over | (s_all_cols > 0x7fffffffull ? 4u : 0u);  // (col_off is an int)
     g->max_tiles = s_max_tiles;
+    g->max_tiles16 = s_max_tiles16;
+    g->sum_tiles = s_sum_tiles;
     g->total_ccols = s_carry2;
   }
 }

@@ -340,7 +340,7 @@ __device__ __forceinline__ void load_slab(const FrameInfo& F, float zlo_h, float
 //     slabs always fit (a cell holds one down-sampled point).
 // Written as a state machine so that the caller's per-region body exists once in the kernel.
 // Every decision is block-uniform.
-template <bool WITH_FIT, int HALO>
+template <bool WITH_FIT, int HALO, int SIDE>
 struct TileWalker {
   const FrameInfo& F;
   const float4* spt;
@@ -349,23 +349,26 @@ struct TileWalker {
   TileShared<WITH_FIT, HALO>& S;
   int halo_xy;   // xy halo of the slab regions (<= HALO)
   float zhalo, leaf_z;
-  int SX, SY;    // the super tile
+  static constexpr int side = SIDE;  // kSuper: the block owns a super tile; kTile: one 16x16 tile (dense clouds; the host picks)
+  int SX, SY;    // the block's tile
   int X0 = 0, Y0 = 0;  // the current 16x16 tile
   int stage = 0, a = 0, b = 0, sub = 0;
   bool in8 = false, in4 = false, in4walk = false, in16 = false;
   int x8 = 0, y8 = 0, x4 = 0, y4 = 0, h8 = 1, h4 = 1;
   float z8 = 0.f, zend8 = 0.f, zs8 = 0.f, ze8 = 0.f, z4 = 0.f, zend4 = 0.f;
 
-  __device__ __forceinline__ TileWalker(const FrameInfo& F_, int tile, int halo_xy_, float zhalo_, float leaf_z_,
-                                        const float4* spt_, const uint32_t* col_first_, const int* fit_rank_,
-                                        TileShared<WITH_FIT, HALO>& S_)
+  __device__ __forceinline__ TileWalker(const FrameInfo& F_, int tile, int halo_xy_, float zhalo_,
+                                        float leaf_z_, const float4* spt_, const uint32_t* col_first_,
+                                        const int* fit_rank_, TileShared<WITH_FIT, HALO>& S_)
       : F(F_), spt(spt_), col_first(col_first_), fit_rank(fit_rank_), S(S_), halo_xy(halo_xy_), zhalo(zhalo_),
         leaf_z(leaf_z_)
   {
-    const int ntx = (F.div_b[0] + kSuper - 1) / kSuper;
+    static_assert(SIDE == kSuper || SIDE == kTile, "tile side");
+    const int ntx = (F.div_b[0] + side - 1) / side;
     const int ty = tile / ntx;
-    SX = (tile - ty * ntx) * kSuper;
-    SY = ty * kSuper;
+    SX = (tile - ty * ntx) * side;
+    SY = ty * side;
+    if (side != kSuper) stage = 1;  // (no super tile to try)
   }
 
   // slab height (cells) from the mean number of points per z layer of the region
@@ -397,8 +400,8 @@ struct TileWalker {
       }
       if (stage == 2) break;
       if (!in16) {
-        // the next 16x16 tile of the super tile
-        if (sub == 4) break;
+        // the next 16x16 tile of the super tile (or the block's only one)
+        if (sub == (side == kSuper ? 4 : 1)) break;
         X0 = SX + (sub & 1) * kTile;
         Y0 = SY + (sub >> 1) * kTile;
         ++sub;
@@ -781,21 +784,22 @@ __device__ __forceinline__ float4 estimate_normal(const Cols& cols, const float4
 }
 
 // grid = (max tiles per frame, n_frames)
-template <int CAPL>
+template <int CAPL, int SIDE>
 __global__ void __launch_bounds__(kBlock, 3)
 k_normals_tile(const float4* spt, const uint32_t* col_first, const FrameInfo* fi, float inv_xy, float inv_z,
                float radius, float r2, int ring, unsigned own_lo, unsigned own_hi, float4* normals, int ablate)
 {
+  constexpr int side = SIDE;
   __shared__ TileShared<false, kHaloNormals> S;
   __shared__ unsigned short s_cand_e[CAPL * kBlock];
   const FrameInfo& F = fi[blockIdx.y];
   const int dx = F.div_b[0], dy = F.div_b[1];
-  if (F.n_vox <= 0 || (int)blockIdx.x >= ((dx + kSuper - 1) / kSuper) * ((dy + kSuper - 1) / kSuper)) return;
+  if (F.n_vox <= 0 || (int)blockIdx.x >= ((dx + side - 1) / side) * ((dy + side - 1) / side)) return;
   const float leaf_z = 1.0f / inv_z;
   unsigned short* cand_e = s_cand_e + threadIdx.x;
   const GlobalCols gc{spt, col_first, nullptr, (unsigned)F.col_off, dx};
   const float zhalo = radius + 2.5f * leaf_z;
-  TileWalker<false, kHaloNormals> walk(F, (int)blockIdx.x, kHaloNormals, zhalo, leaf_z, spt, col_first, nullptr, S);
+  TileWalker<false, kHaloNormals, SIDE> walk(F, (int)blockIdx.x, kHaloNormals, zhalo, leaf_z, spt, col_first, nullptr, S);
   TileGeom g;
   while (walk.next(g)) {
     if (ablate == 1) continue;
@@ -915,24 +919,25 @@ constexpr uint32_t kTodoFromRing0 = 0x80000000u;  // todo flag: only part of rin
 // Phase A, grid = (max tiles per frame, n_frames): every query whose k neighbours provably lie
 // inside the LDS copy of its tile is answered here; the others (sparse neighbourhoods) are
 // appended to `todo` and answered by k_knn_todo.
-template <int KMAX>
+template <int KMAX, int SIDE>
 __global__ void __launch_bounds__(kBlock, KMAX <= 8 ? 4 : 1)
 k_knn_tile(const float4* spt, const uint32_t* col_first, const int* fit_rank, const FrameInfo* fi, float inv_xy,
            float inv_z, float cell_xy, int K, const uint32_t* fit_idx, unsigned own_lo, unsigned own_hi, int* knn_out,
            uint32_t* todo, unsigned* n_todo, int ablate)
 {
+  constexpr int side = SIDE;
   typedef TileCols<kHaloKnn> Tc;
   __shared__ TileShared<true, kHaloKnn> S;
   const FrameInfo& F = fi[blockIdx.y];
   const int dx = F.div_b[0], dy = F.div_b[1];
-  if (F.n_fit <= 0 || (int)blockIdx.x >= ((dx + kSuper - 1) / kSuper) * ((dy + kSuper - 1) / kSuper)) return;
+  if (F.n_fit <= 0 || (int)blockIdx.x >= ((dx + side - 1) / side) * ((dy + side - 1) / side)) return;
   const float leaf_z = 1.0f / inv_z;
   const int k = min(K, F.n_fit);
   // Fast pass: the 5x5 square is ring 2; a list that settles there holds only neighbours closer
   // than reach2, so a z window of that height loses nothing.
   const float reach2 = ring_reach(2, F.slack, cell_xy);
   const float zwin = reach2 + 1.5f * leaf_z;
-  TileWalker<true, kHaloKnn> walk(F, (int)blockIdx.x, 2, zwin + leaf_z, leaf_z, spt, col_first, fit_rank, S);
+  TileWalker<true, kHaloKnn, SIDE> walk(F, (int)blockIdx.x, 2, zwin + leaf_z, leaf_z, spt, col_first, fit_rank, S);
   TileGeom g;
   while (walk.next(g)) {
     const Tc tc{S.pt, S.tab, g.xh0, g.yh0};

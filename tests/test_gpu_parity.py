@@ -284,6 +284,28 @@ def test_group_records_through_the_segmented_sort(hip_lib, oracle_lib, monkeypat
     assert_frame_equal(o, g, 0)
 
 
+def test_neighbour_tile_side(hip_lib, oracle_lib, monkeypatch):
+    """The neighbour kernels give a workgroup a 32x32-column super tile (sparse frames) or one 16x16 tile (dense
+    clouds); the library picks per call from the points per super tile, the knob forces either.  Same bits."""
+    from hope_amd import synth
+    depth, t, q = synth_frames(2, first=61)
+    xyz = synth.make_multilevel_cloud(200000, first_index=99, device="cpu").numpy()
+    o, oc = HopeContext(oracle_lib), HopeContext(oracle_lib)
+    o.set_frame_poses(t, q)
+    o.segment_depth(depth)
+    oc.segment_cloud(xyz)
+    for side in ("16", "32"):
+        monkeypatch.setenv("HOPE_DEBUG_TILE_SIDE", side)
+        g = HopeContext(hip_lib)
+        monkeypatch.delenv("HOPE_DEBUG_TILE_SIDE")
+        g.set_frame_poses(t, q)
+        g.segment_depth(depth)
+        for f in range(2):
+            assert_frame_equal(o, g, f)
+        g.segment_cloud(xyz)
+        assert_frame_equal(oc, g, 0)
+
+
 def test_depth_frames_through_two_passes(hip_lib, oracle_lib, monkeypatch):
     """Depth frames normally take one pass over the batch (k_bbox_records: records with packed cell codes in
     sparse slots, keys made once the bounding box is known).  The knob forces the two-pass path
