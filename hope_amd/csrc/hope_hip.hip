@@ -705,7 +705,10 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   // would only be four tiles run one after the other by a quarter of the workgroups (config 4, 2800 points per
   // super tile: normals 12.2 instead of 6.3 ms)
   const unsigned sum_tiles = std::max(1u, c->h_glob->sum_tiles);
-  const auto tile_side = [&](size_t points) { return points <= (size_t)kTileCap * 2 / 3 * sum_tiles ? kSuper : kTile; };
+  // -- and only when there are enough super tiles to fill the chip (a single 640x480 frame has ~20: 1.08 -> 1.44 ms)
+  const auto tile_side = [&](size_t points) {
+    return sum_tiles >= 1024u && points <= (size_t)kTileCap * 2 / 3 * sum_tiles ? kSuper : kTile;
+  };
   const auto tile_grid_of = [&](int side) {
     return dim3(std::max(1u, side == kSuper ? c->h_glob->max_tiles : c->h_glob->max_tiles16), F);
   };
