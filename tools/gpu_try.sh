@@ -19,3 +19,14 @@ print(sys.argv[1].split('/')[-1], 'value %.4g pts/s  %.3f ms/step' % (d['value']
 print('  ' + '  '.join(f"{s['stage'].split('(')[0]}={s['ms_per_step']:.2f}" for s in d['stages']))
 PY
 done
+if [ -n "$ALL" ]; then  # the other workloads too: a change that helps the frame batch can hurt these
+  timeout -k 10 300 python bench.py --workload cloud --no-cpu-baseline > $O/cloud_$tag.log 2>&1 || { tail -5 $O/cloud_$tag.log; exit 1; }
+  timeout -k 10 200 python tools/bench_rt.py > $O/rt_$tag.json 2> $O/rt_$tag.err || { tail -5 $O/rt_$tag.err; exit 1; }
+  python - $O/cloud_$tag.log $O/rt_$tag.json <<'PY'
+import json, sys
+d = json.loads([x for x in open(sys.argv[1]) if x.startswith('{')][-1])
+print('cloud 1e8: %.2f ms  ' % d['ms_per_step'] + '  '.join(f"{s['stage'].split('(')[0]}={s['ms_per_step']:.2f}" for s in d['stages']))
+r = json.loads([x for x in open(sys.argv[2]) if x.startswith('{')][-1])
+print('streamed frame: p50 %.2f ms  p99 %.2f ms' % (r['p50_ms'], r['p99_ms']))
+PY
+fi
