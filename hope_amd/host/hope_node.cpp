@@ -11,9 +11,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <fstream>
+#include <future>
 #include <iostream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "formats.hpp"
@@ -219,33 +222,57 @@ int main(int argc, char** argv)
     // overwritten per line, hope_node.cpp:88-90, and read after the loop, :231); the quaternion is per frame.
     const TumEntry& last = list.back();
     const size_t kBatch = 256;                 // frames per device call; 157 MB of depth
-    std::vector<uint16_t> depth_batch;
-    std::vector<float> t, q;
+    // The device needs ~12 us per frame, inflating a 16-bit PNG ~2 ms: the images of a batch are decoded by all
+    // host threads at once, and the next batch is decoded while the device works on the current one.
+    struct Batch {
+      std::vector<uint16_t> depth;
+      std::vector<float> t, q;
+      std::vector<std::string> names, messages;
+      int w = 0, h = 0;
+    };
+    const unsigned n_workers = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    auto load_batch = [&](size_t b0, size_t b1) {
+      const size_t n = b1 - b0;
+      std::vector<std::vector<uint16_t>> img(n);
+      std::vector<int> wi(n, 0), hi(n, 0);
+      std::vector<std::string> errs(n);
+      std::vector<char> ok(n, 0);
+      std::atomic<size_t> next{0};
+      std::vector<std::thread> pool;
+      for (unsigned k = 0; k < std::min<size_t>(n_workers, n); ++k)
+        pool.emplace_back([&] {
+          for (size_t i = next++; i < n; i = next++)
+            ok[i] = readDepthPng(path_prefix + "/" + list[b0 + i].depth, img[i], wi[i], hi[i], errs[i]) ? 1 : 0;
+        });
+      for (std::thread& th : pool) th.join();
+      Batch b;
+      for (size_t i = 0; i < n; ++i) {   // (in list order, with upstream's messages)
+        if (!ok[i]) { b.messages.push_back(errs[i]); continue; }
+        if (b.w == 0) { b.w = wi[i]; b.h = hi[i]; }
+        if (wi[i] != b.w || hi[i] != b.h) { b.messages.push_back(list[b0 + i].depth + ": image size differs from the batch, skipped"); continue; }
+        b.depth.insert(b.depth.end(), img[i].begin(), img[i].end());
+        b.t.insert(b.t.end(), last.t, last.t + 3);
+        b.q.insert(b.q.end(), list[b0 + i].q, list[b0 + i].q + 4);
+        b.names.push_back(list[b0 + i].rgb);
+      }
+      return b;
+    };
     double total_ms = 0;
     size_t done = 0;
+    std::future<Batch> ahead = std::async(std::launch::async, load_batch, (size_t)0, std::min(list.size(), kBatch));
     for (size_t b0 = 0; b0 < list.size(); b0 += kBatch) {
-      const size_t b1 = std::min(list.size(), b0 + kBatch);
-      int w = 0, h = 0;
-      depth_batch.clear(); t.clear(); q.clear();
-      std::vector<std::string> names;
-      for (size_t i = b0; i < b1; ++i) {
-        std::vector<uint16_t> d; int wi, hi;
-        if (!readDepthPng(path_prefix + "/" + list[i].depth, d, wi, hi, err)) { std::cerr << err << std::endl; continue; }
-        if (w == 0) { w = wi; h = hi; }
-        if (wi != w || hi != h) { std::cerr << list[i].depth << ": image size differs from the batch, skipped" << std::endl; continue; }
-        depth_batch.insert(depth_batch.end(), d.begin(), d.end());
-        t.insert(t.end(), last.t, last.t + 3);
-        q.insert(q.end(), list[i].q, list[i].q + 4);
-        names.push_back(list[i].rgb);
-      }
-      if (names.empty()) continue;
-      hope.getHorizontalPlanesBatch(depth_batch.data(), w, h, (int)names.size(), t.data(), q.data(), [&](int f) {
-        std::cout << "Processing: " << names[f] << std::endl;
-        report(hope, names[f], dump);
+      Batch b = ahead.get();
+      const size_t n0 = b0 + kBatch;
+      if (n0 < list.size()) ahead = std::async(std::launch::async, load_batch, n0, std::min(list.size(), n0 + kBatch));
+      for (const std::string& m : b.messages) std::cerr << m << std::endl;
+      if (b.names.empty()) continue;
+      hope.getHorizontalPlanesBatch(b.depth.data(), b.w, b.h, (int)b.names.size(), b.t.data(), b.q.data(), [&](int f) {
+        std::cout << "Processing: " << b.names[f] << std::endl;
+        report(hope, b.names[f], dump);
       });
       if (hope.last_status() < 0) return 1;
       total_ms += hope.last_ms();
-      done += names.size();
+      done += b.names.size();
     }
     std::printf("[TIMER]: %zu frames, %.3f ms in the library, %.4f ms per frame\n", done, total_ms, done ? total_ms / done : 0.0);
   } catch (const std::exception& e) {
