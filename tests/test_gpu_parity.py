@@ -588,6 +588,15 @@ def test_invalid_arguments(hip_lib):
     cnt = HopeCounts()
     assert hip_lib.fn["frame_counts"](g._h, 5, C.byref(cnt)) < 0
     assert b"range" in hip_lib.fn["last_error"](g._h)
+    # the round-2 entry points refuse what they cannot serve, on both libraries alike
+    n64 = C.c_int64(0)
+    pos = (C.c_int32 * 4)()
+    assert hip_lib.fn["set_pose_rpy"](None, 0.0, 0.0, 0.0) < 0
+    assert hip_lib.fn["get_cluster_hull_candidates"](g._h, 0, 0, pos, 4) < 0          # the 4-point cloud has no cluster
+    assert hip_lib.fn["get_cluster_hull_candidates"](g._h, 3, 0, pos, 4) < 0          # no such frame
+    assert hip_lib.fn["count_band_crossings"](g._h, 0, 0, 1, C.byref(n64)) < 0        # more fit points than there are
+    assert hip_lib.fn["count_band_crossings"](g._h, 0, 0, 0, None) < 0
+    assert hip_lib.fn["count_band_crossings"](g._h, 0, 0, 0, C.byref(n64)) == 0 and n64.value == 0
 
 
 def test_sub_batches_on_their_own_streams(hip_lib, oracle_lib, monkeypatch):
