@@ -191,6 +191,7 @@ struct hope_ctx {
   int pixel_sort = 0;         // test knob: depth frames through the per-pixel sort (the cloud path's voxel stage)
   int col_sort_z = 0;         // test knob HOPE_DEBUG_COLSORT_Z=1: z cell bits in the column sort key even for VoxelGrid output
   int seg_sort = 1;           // per-frame segmented sort of the group records (HOPE_DEBUG_SEGSORT=0: device-wide sort)
+  int col_index_lds = 1;      // column index by a per-frame counting sort in LDS when the tables fit (HOPE_DEBUG_COL_INDEX=0: the radix sort)
   int tile_side = 0;          // neighbour tiles: 0 = chosen per call from the points per super tile; HOPE_DEBUG_TILE_SIDE=16|32 forces
   int voxel_rank = 1;         // depth batches: voxels ranked by an LDS bitmap per frame instead of sorting the group
                               // records (HOPE_DEBUG_VOXEL_RANK=0, or any knob that asks for a sort: the sorting path)
@@ -679,6 +680,13 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   const int czbits = col_only ? 0 : zbits;
   const int ckey_bits = key2_bits - zbits + czbits;
   size_t pm = prof_mark(c);
+  // frames whose column table fits in LDS (and that are not one huge cloud for a single workgroup): a counting
+  // sort per frame (k_column_index) instead of keys + device-wide radix sort + table + gather
+  if (col_only && c->col_index_lds && c->h_glob->max_cols <= kCntCap && (size_t)n_vox <= (size_t)200000 * F) {
+    hipLaunchKernelGGL(k_column_index, dim3(F), dim3(kRankBlock), 0, s, d_vox, c->d_fi, F, c->inv_xy, n_vox, total_cols,
+                       col_first, cv_in, spt);
+    prof_close(c, ST_COLTABLE, pm, (16.0 + 16.0) * n_vox + 4.0 * total_cols);
+  } else {
   hipLaunchKernelGGL((k_column_keys<CK>), dim3(nblk(n_vox)), dim3(kBlock), 0, s, d_vox, d_vox_frame, c->d_fi,
                      n_vox, c->inv_xy, c->inv_z, czbits, ck_in, cv_in);
   prof_close(c, ST_COLKEYS, pm, (16.0 + 4.0 + sizeof(CK) + 4.0) * n_vox);
@@ -694,6 +702,7 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
                      total_cols, czbits, col_first);
   hipLaunchKernelGGL(k_gather_sorted, dim3(nblk(n_vox)), dim3(kBlock), 0, s, d_vox, cv_out, n_vox, spt);
   prof_close(c, ST_COLTABLE, pm, (4.0 + 16.0 + 16.0) * n_vox + 4.0 * total_cols);
+  }
 
   // ---- A6 normals -----------------------------------------------------------------
   float4* d_normals;
@@ -1242,6 +1251,8 @@ HOPE_API int hope_create(const hope_config* cfg, hope_ctx** out)
   if (knob && std::atoi(knob) >= 1) c->sub_min_frames = std::atoi(knob);
   knob = std::getenv("HOPE_DEBUG_SEGSORT");
   c->seg_sort = (knob && knob[0] == '0') ? 0 : 1;
+  knob = std::getenv("HOPE_DEBUG_COL_INDEX");
+  c->col_index_lds = (knob && knob[0] == '0') ? 0 : 1;
   knob = std::getenv("HOPE_DEBUG_TILE_SIDE");
   if (knob) c->tile_side = std::atoi(knob) == kSuper ? kSuper : (std::atoi(knob) == kTile ? kTile : 0);
   knob = std::getenv("HOPE_DEBUG_VOXEL_RANK");

@@ -54,6 +54,7 @@ struct Globals {  // scalars produced on device, read back at the sync points
   unsigned int max_tiles; // largest per-frame count of 32x32-column super tiles (neighbours.hpp)
   unsigned int max_tiles16;  // ... of 16x16-column tiles
   unsigned int sum_tiles;    // super tiles of all frames (the host picks the tile side from the points per super tile)
+  unsigned int max_cols;     // largest per-frame column table (columns + 1)
   unsigned int total_ccols;  // entries of the coarse column table
   unsigned int n_todo;       // k-NN queries left over by the tile pass
   unsigned int max_fit;      // largest per-frame count of fit points
@@ -207,7 +208,7 @@ __global__ void __launch_bounds__(1024) k_frame_grid(FrameInfo* fi, int n_frames
   __shared__ unsigned s_scan[1024];
   __shared__ unsigned long long s_max_cells;
   __shared__ unsigned long long s_all_cols;
-  __shared__ unsigned s_max_dz, s_any_over, s_carry, s_carry2, s_max_tiles, s_max_tiles16, s_sum_tiles;
+  __shared__ unsigned s_max_dz, s_any_over, s_carry, s_carry2, s_max_tiles, s_max_tiles16, s_sum_tiles, s_max_cols;
   const int tid = threadIdx.x;
   if (tid == 0) {
     s_all_cols = 0;
@@ -219,6 +220,7 @@ __global__ void __launch_bounds__(1024) k_frame_grid(FrameInfo* fi, int n_frames
     s_max_tiles = 0;
     s_max_tiles16 = 0;
     s_sum_tiles = 0;
+    s_max_cols = 0;
   }
   __syncthreads();
   for (int base = 0; base < n_frames; base += 1024) {
@@ -301,7 +303,10 @@ __global__ void __launch_bounds__(1024) k_frame_grid(FrameInfo* fi, int n_frames
       __syncthreads();
     }
     const unsigned carry = s_carry;
-    if (f < n_frames) fi[f].col_off = (int)(carry + s_scan[tid] - ncols);
+    if (f < n_frames) {
+      fi[f].col_off = (int)(carry + s_scan[tid] - ncols);
+      atomicMax(&s_max_cols, ncols);
+    }
     __syncthreads();
     if (tid == 1023) s_carry = carry + s_scan[1023];
     __syncthreads();
@@ -328,6 +333,7 @@ __global__ void __launch_bounds__(1024) k_frame_grid(FrameInfo* fi, int n_frames
     g->max_tiles = s_max_tiles;
     g->max_tiles16 = s_max_tiles16;
     g->sum_tiles = s_sum_tiles;
+    g->max_cols = s_max_cols;
     g->total_ccols = s_carry2;
   }
 }

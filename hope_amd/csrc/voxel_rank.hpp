@@ -222,6 +222,100 @@ k_frame_vox_scan(FrameInfo* fi, int n_frames, const uint32_t* vox_cnt, uint32_t*
   }
 }
 
+// ---- the column index of A6 / A8 without a sort ------------------------------------------------------------------
+// The searches want the down-sampled points of a frame grouped by xy column, every column ascending in z cell, and
+// the table of column starts.  VoxelGrid's output already ascends in z cell, so a STABLE counting sort by column
+// does it, and a frame's columns (a few ten thousand) fit in LDS as counters: one workgroup per frame counts the
+// points of every column, scans, and gives each point the next free place of its column -- in arrival order, so
+// a last pass moves every point to its place in index order (idx_tmp: n_vox indices of scratch).
+// Replaces k_column_keys + the device-wide radix sort + k_column_table + k_gather_sorted for frames whose table
+// (columns + 1) fits kCntCap counters.  grid = n_frames, block = kRankBlock.
+__global__ void __launch_bounds__(kRankBlock)
+k_column_index(const float4* vox, const FrameInfo* fi, int n_frames, float inv_xy, unsigned n_vox_total,
+               unsigned total_cols, uint32_t* col_first, uint32_t* idx_tmp, float4* spt)
+{
+  __shared__ unsigned s_cnt[kCntCap];
+  __shared__ unsigned s_w[kRankBlock / kWave + 1];
+  const FrameInfo& F = fi[blockIdx.x];
+  const unsigned tid = threadIdx.x;
+  const int dx = F.div_b[0], dy = F.div_b[1];
+  const unsigned T = (unsigned)(dx * dy) + 1u;  // (the last entry closes the frame's part of the table)
+  const unsigned n = (unsigned)F.n_vox, base = (unsigned)F.vox_start;
+  if (blockIdx.x == (unsigned)n_frames - 1u && tid == 0) col_first[total_cols] = n_vox_total;
+  for (unsigned i = tid; i < T; i += kRankBlock) s_cnt[i] = 0u;
+  __syncthreads();
+  const float4* pv = vox + base;
+  auto column = [&](const float4& p) {
+    const int cx = clampi(cell_unclamped(p.x, inv_xy, F.min_b[0]), 0, dx - 1);
+    const int cy = clampi(cell_unclamped(p.y, inv_xy, F.min_b[1]), 0, dy - 1);
+    return (unsigned)(cy * dx + cx);
+  };
+  // (four loads in flight per thread: a pass is a handful of dependent round trips to HBM otherwise)
+  for (unsigned i0 = tid; i0 < n; i0 += 4u * kRankBlock) {
+    float4 p[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) p[u] = pv[min(i0 + (unsigned)u * kRankBlock, n - 1u)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i0 + (unsigned)u * kRankBlock < n) atomicAdd(&s_cnt[column(p[u])], 1u);
+  }
+  __syncthreads();
+  const unsigned per = (T + kRankBlock - 1u) / kRankBlock;
+  unsigned sum = 0u;
+  for (unsigned k = 0; k < per; ++k) {
+    const unsigned c = tid * per + k;
+    if (c < T) sum += s_cnt[c];
+  }
+  unsigned total;
+  unsigned at = block_scan_excl_1024(sum, s_w, total);
+  uint32_t* cf = col_first + (unsigned)F.col_off;
+  for (unsigned k = 0; k < per; ++k) {
+    const unsigned c = tid * per + k;
+    if (c < T) {
+      const unsigned cnt = s_cnt[c];
+      s_cnt[c] = at;
+      at += cnt;
+    }
+  }
+  __syncthreads();
+  for (unsigned c = tid; c < T; c += kRankBlock) cf[c] = base + s_cnt[c];  // (coalesced)
+  __syncthreads();  // (the placement below advances the counters)
+  // every point takes the next free place of its column (arrival order) and leaves its index there ...
+  uint32_t* pi = idx_tmp + base;
+  for (unsigned i0 = tid; i0 < n; i0 += 4u * kRankBlock) {
+    float4 p[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) p[u] = pv[min(i0 + (unsigned)u * kRankBlock, n - 1u)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned i = i0 + (unsigned)u * kRankBlock;
+      if (i < n) pi[atomicAdd(&s_cnt[column(p[u])], 1u)] = i;
+    }
+  }
+  __syncthreads();  // (s_cnt[c] is now one past column c's last place; the indices are visible to the workgroup)
+  // ... then moves to its place in INDEX order: first place of the column + the number of the column's points with
+  // a smaller index (columns hold one point, often two, rarely a wall's worth: no chain of dependent loads either way)
+  float4* ps = spt + base;
+  for (unsigned i0 = tid; i0 < n; i0 += 4u * kRankBlock) {
+    float4 p[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) p[u] = pv[min(i0 + (unsigned)u * kRankBlock, n - 1u)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned i = i0 + (unsigned)u * kRankBlock;
+      if (i < n) {
+        const unsigned c = column(p[u]);
+        const unsigned a = c > 0u ? s_cnt[c - 1u] : 0u, b = s_cnt[c];
+        unsigned rank = 0u;
+        if (b - a > 1u)
+          for (unsigned j = a; j < b; ++j) rank += pi[j] < i ? 1u : 0u;
+        p[u].w = __uint_as_float(base + i);  // (the PCL-order index, as k_gather_sorted leaves it)
+        ps[a + rank] = p[u];
+      }
+    }
+  }
+}
+
 // Centroids (CentroidPoint<PointXYZ>: sequential float sum / n) from the per-voxel record lists: one lane per
 // voxel, one block per kBlock voxels of a frame (k_frame_vox_scan lays the blocks out).  The lists of a block's voxels are one contiguous range
 // of rec_list: copied to LDS, each sorted by its lane (a few entries), then walked exactly as

@@ -413,6 +413,28 @@ def test_column_sort_with_and_without_the_z_cell(hip_lib, oracle_lib, monkeypatc
         assert_frame_equal(o, g2, f)
 
 
+def test_column_index_by_counting_sort_or_radix_sort(hip_lib, oracle_lib, monkeypatch):
+    """Frames whose column table fits in LDS get their column index from a per-frame counting sort
+    (k_column_index); the knob sends them through keys + radix sort + table + gather, which larger grids take by
+    themselves.  A cloud with tall columns (the loft: walls) exercises the put-back-in-order step."""
+    depth, t, q = synth_frames(3, first=61)
+    xyz = np.load(os.path.join(GOLDEN, "loft_120k.npz"))["xyz"]
+    monkeypatch.setenv("HOPE_DEBUG_COL_INDEX", "0")
+    g = HopeContext(hip_lib)
+    monkeypatch.delenv("HOPE_DEBUG_COL_INDEX")
+    g2, o, oc = HopeContext(hip_lib), HopeContext(oracle_lib), HopeContext(oracle_lib)
+    oc.segment_cloud(xyz)
+    for c in (g, g2, o):
+        c.set_frame_poses(t, q)
+        assert c.segment_depth(depth) == 0
+    for f in range(3):
+        assert_frame_equal(o, g, f)
+        assert_frame_equal(o, g2, f)
+    for c in (g, g2):
+        c.segment_cloud(xyz)
+        assert_frame_equal(oc, c, 0)
+
+
 def test_knn_leftovers_through_the_coarse_index(hip_lib, oracle_lib, monkeypatch):
     """k-NN queries that the LDS tile cannot settle go through a whole-frame ring expansion: over the
     fine column index when few, over the coarse index of the fit points when many.  The knob sets the
