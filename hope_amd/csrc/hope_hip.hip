@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -163,7 +164,12 @@ struct hope_ctx {
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   Arena arena;
   Globals* d_glob = nullptr;
-  Globals* h_glob = nullptr;  // pinned
+  Globals* h_glob = nullptr;  // pinned, mapped, host-coherent: written by k_publish_globals (or a D2H copy)
+  Globals* h_glob_dev = nullptr;  // the device's address of it
+  unsigned* h_seq = nullptr;      // sequence number of the last publication, in the same allocation
+  unsigned* h_seq_dev = nullptr;
+  unsigned mail_seq = 0;
+  int mail_poll = 1;          // HOPE_DEBUG_SYNC=memcpy: D2H copy + stream synchronisation instead of the polled mailbox
   StaticScratch* d_scratch = nullptr;  // this device's copy of `scratch` (no-allocation entry point)
   Pose pose;
   std::vector<Pose> frame_poses;
@@ -305,10 +311,48 @@ void make_affine(const Pose& p, float* a)
   a[11] = p.t[2];
 }
 
+// The counts that size the next launches come back to the host several times per call.  A D2H copy plus a stream
+// synchronisation costs tens of microseconds of idle GPU each time; instead a one-wave kernel, ordered on the stream
+// like the copy would be, writes the scalars straight into pinned, host-coherent memory and then a sequence number,
+// which the host polls (falling back to a stream synchronisation, which also surfaces any error of an earlier kernel).
+__global__ void k_publish_globals(const Globals* d, Globals* h, unsigned* h_seq, unsigned seq)
+{
+  const unsigned* src = reinterpret_cast<const unsigned*>(d);
+  unsigned* dst = reinterpret_cast<unsigned*>(h);
+  for (unsigned i = threadIdx.x; i < sizeof(Globals) / sizeof(unsigned); i += blockDim.x) dst[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __atomic_store_n(h_seq, seq, __ATOMIC_RELEASE);
+    __threadfence_system();
+  }
+}
+
 int sync_globals(hope_ctx* c)
 {
-  HIPCHK(hipMemcpyAsync(c->h_glob, c->d_glob, sizeof(Globals), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  if (!c->mail_poll) {
+    HIPCHK(hipMemcpyAsync(c->h_glob, c->d_glob, sizeof(Globals), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return HOPE_OK;
+  }
+  const unsigned seq = ++c->mail_seq;
+  hipLaunchKernelGGL(k_publish_globals, dim3(1), dim3(kWave), 0, c->stream, c->d_glob, c->h_glob_dev, c->h_seq_dev, seq);
+  volatile unsigned* hs = c->h_seq;
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  while (*hs != seq) {
+    if ((++spins & 1023u) == 0u &&
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05) {
+      HIPCHK(hipStreamSynchronize(c->stream));  // (long kernels, or an error on the stream)
+      if (*hs != seq) {
+        c->err = "the count read-back kernel did not run";
+        return HOPE_E_HIP;
+      }
+      break;
+    }
+    __builtin_ia32_pause();
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
   return HOPE_OK;
 }
 
@@ -1209,9 +1253,23 @@ HOPE_API int hope_create(const hope_config* cfg, hope_ctx** out)
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&c->ev_a) != hipSuccess || hipEventCreate(&c->ev_b) != hipSuccess ||
       hipMalloc((void**)&c->d_glob, sizeof(Globals)) != hipSuccess ||
-      hipHostMalloc((void**)&c->h_glob, sizeof(Globals)) != hipSuccess) {
+      hipHostMalloc((void**)&c->h_glob, sizeof(Globals) + 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
     delete c;
     return HOPE_E_HIP;
+  }
+  std::memset(c->h_glob, 0, sizeof(Globals) + 64);
+  c->h_seq = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(c->h_glob) + (sizeof(Globals) + 15) / 16 * 16);
+  {
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, c->h_glob, 0) == hipSuccess && dp) {
+      c->h_glob_dev = static_cast<Globals*>(dp);
+      c->h_seq_dev = reinterpret_cast<unsigned*>(static_cast<char*>(dp) + (reinterpret_cast<char*>(c->h_seq) - reinterpret_cast<char*>(c->h_glob)));
+    } else {
+      (void)hipGetLastError();
+      c->mail_poll = 0;
+    }
+    const char* sk = std::getenv("HOPE_DEBUG_SYNC");
+    if (sk && std::strcmp(sk, "memcpy") == 0) c->mail_poll = 0;
   }
   {
     // the device's address of the static scratch array, once per device, with that device current
