@@ -320,7 +320,7 @@ k_column_index(const float4* vox, const FrameInfo* fi, int n_frames, float inv_x
 // voxel, one block per kBlock voxels of a frame (k_frame_vox_scan lays the blocks out).  The lists of a block's voxels are one contiguous range
 // of rec_list: copied to LDS, each sorted by its lane (a few entries), then walked exactly as
 // k_centroids_groups walks the sorted records.
-constexpr int kListCap = 6144;  // entries of LDS per block (24 KiB); a block with more sorts and walks in HBM
+constexpr int kListCap = 2048;  // entries of LDS per block (8 KiB: 256 voxels of ~3 records; occupancy is then bounded by registers, not LDS); a block with more sorts and walks in HBM
 
 template <class ListPtr>
 __device__ __forceinline__ void sort_small(ListPtr list, unsigned n)
