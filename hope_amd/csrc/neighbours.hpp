@@ -697,7 +697,7 @@ template <class Cols, int N>
 __device__ __forceinline__ void accumulate_sorted(const Cols& cols, const float4 q, const unsigned short* cand_e,
                                                   int total, float* accu)
 {
-  static_assert(N == 16 || N == 32, "sorting networks exist for 16 and 32 inputs");
+  static_assert(N == 8 || N == 12 || N == 16 || N == 32, "sorting networks exist for 8, 12, 16 and 32 inputs");
   float cd[N];
   unsigned ce[N];
 #pragma unroll
@@ -707,7 +707,11 @@ __device__ __forceinline__ void accumulate_sorted(const Cols& cols, const float4
     const float4 p = cols.pt(ce[s]);
     cd[s] = s < total ? dist2(q.x, q.y, q.z, p.x, p.y, p.z) : INFINITY;
   }
-  if (N == 16) {
+  if (N == 8) {
+    HOPE_SORT_NET8
+  } else if (N == 12) {
+    HOPE_SORT_NET12
+  } else if (N == 16) {
     HOPE_SORT_NET16
   } else {
     HOPE_SORT_NET32
@@ -744,8 +748,13 @@ __device__ __forceinline__ float4 estimate_normal(const Cols& cols, const float4
   if (ablate == 2) return make_float4((float)total, 0.f, 0.f, 0.f);
   float accu[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (Cols::kLds && total <= CAPL) {
-    // wave-uniform choice of the network: 16 inputs unless some lane of the wave has more
-    if (CAPL <= 16 || !__any(total > 16))
+    // wave-uniform choice of the network: the smallest one that holds the longest list of the wave (a horizontal
+    // surface finds 5..10 neighbours)
+    if (CAPL <= 8 || !__any(total > 8))
+      accumulate_sorted<Cols, 8>(cols, q, cand_e, total, accu);
+    else if (CAPL <= 12 || !__any(total > 12))
+      accumulate_sorted<Cols, 12>(cols, q, cand_e, total, accu);
+    else if (CAPL <= 16 || !__any(total > 16))
       accumulate_sorted<Cols, 16>(cols, q, cand_e, total, accu);
     else
       accumulate_sorted<Cols, 32>(cols, q, cand_e, total, accu);
