@@ -50,6 +50,7 @@ def parse_args():
     ap.add_argument("--cpu-frames", type=int, default=256, help="frames timed through the CPU oracle on one core")
     ap.add_argument("--cpu-points", type=int, default=2_000_000, help="cloud workload: points of the oracle's sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hip-lib", default=None, help="diagnostics only: another build of libhope_hip.so (tools/ablate.sh)")
     return ap.parse_args()
 
 
@@ -187,7 +188,7 @@ def main():
     from hope_amd import synth
     from hope_amd.capi import HopeContext, HopeLib
 
-    ctx = HopeContext(HopeLib(), device=local_rank)
+    ctx = HopeContext(HopeLib(args.hip_lib) if args.hip_lib else HopeLib(), device=local_rank)
 
     if args.workload == "frames":
         # ---- synthetic batch, generated on the device (config 2; rank r gets frames r*F .. r*F+F-1)
