@@ -306,6 +306,26 @@ def test_neighbour_tile_side(hip_lib, oracle_lib, monkeypatch):
         assert_frame_equal(oc, g, 0)
 
 
+def test_count_read_backs_by_mailbox_or_copy(hip_lib, oracle_lib, monkeypatch):
+    """The counts that size the next launches reach the host through a polled mailbox in pinned host memory
+    (k_publish_globals); the knob restores the D2H copy + stream synchronisation.  Same results either way, and a ctx
+    of each kind can be used in turn."""
+    depth, t, q = synth_frames(2, first=71)
+    o = HopeContext(oracle_lib)
+    o.set_frame_poses(t, q)
+    o.segment_depth(depth)
+    monkeypatch.setenv("HOPE_DEBUG_SYNC", "memcpy")
+    g0 = HopeContext(hip_lib)
+    monkeypatch.delenv("HOPE_DEBUG_SYNC")
+    g1 = HopeContext(hip_lib)
+    for rep in range(2):
+        for g in (g0, g1):
+            g.set_frame_poses(t, q)
+            assert g.segment_depth(depth) == 0
+            for f in range(2):
+                assert_frame_equal(o, g, f)
+
+
 def test_depth_frames_through_two_passes(hip_lib, oracle_lib, monkeypatch):
     """Depth frames normally take one pass over the batch (k_bbox_records: records with packed cell codes in
     sparse slots, keys made once the bounding box is known).  The knob forces the two-pass path
