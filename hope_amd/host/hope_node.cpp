@@ -156,7 +156,9 @@ int main(int argc, char** argv)
 #ifdef HOPE_NODE_MULTI_GPU
       // HOPE_NODE_GPUS=N: the cloud in N contiguous ranges, one thread, ctx and RCCL communicator per GPU
       // (rccl_comm.cpp / multi_gpu.cpp; exchanges as in DESIGN.md section 7).  No counterpart upstream.
-      if (const char* g = std::getenv("HOPE_NODE_GPUS")) {
+      const char* on0 = std::getenv("HOPE_NODE_RANKS_ON_GPU0");   // (one-GPU boxes: N ranks as threads on device 0, no RCCL)
+      const char* g = on0 ? on0 : std::getenv("HOPE_NODE_GPUS");
+      if (g) {
         const int n_gpus = std::atoi(g);
         hope_config cfg;
         hope_config_default(&cfg);
@@ -166,7 +168,8 @@ int main(int argc, char** argv)
           xyz[3 * i] = src_cloud->points[i].x; xyz[3 * i + 1] = src_cloud->points[i].y; xyz[3 * i + 2] = src_cloud->points[i].z;
         }
         MultiResult m;
-        const int st = run_cloud_on_gpus(n_gpus, cfg, xyz.data(), src_cloud->size(), 0, nullptr, nullptr, m, err);   // POINT_CLOUD: no filter, no pose (:118-120)
+        const int st = on0 ? run_cloud_as_ranks_on_gpu0(n_gpus, cfg, xyz.data(), src_cloud->size(), 0, m, err)
+                           : run_cloud_on_gpus(n_gpus, cfg, xyz.data(), src_cloud->size(), 0, nullptr, nullptr, m, err);   // POINT_CLOUD: no filter, no pose (:118-120)
         if (st < 0) { std::cerr << "HoPE multi-GPU: " << err << std::endl; return 1; }
         std::vector<std::vector<float>> coeff;
         std::vector<int> points;

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
+#include <cstring>
 #include <stdexcept>
 #include <thread>
 
@@ -87,7 +89,131 @@ class RcclComm : public Comm {
   hipStream_t stream_ = nullptr;
 };
 
+// threads + device buffers on one GPU: ThreadComm's rendezvous, hipMemcpy as the transport
+class DeviceThreadComm : public Comm {
+ public:
+  DeviceThreadComm(ThreadGroup& g, int rank) : g_(g), rank_(rank) {}
+  int rank() const override { return rank_; }
+  int world() const override { return g_.world(); }
+  int on_device() const override { return 1; }
+  void* alloc(size_t bytes) override
+  {
+    void* p = nullptr;
+    HIP_OK(hipSetDevice(0));
+    HIP_OK(hipMalloc(&p, bytes ? bytes : 1));
+    return p;
+  }
+  void release(void* p) override { (void)hipFree(p); }
+  void put(void* d, const void* s, size_t b) override { if (b) HIP_OK(hipMemcpy(d, s, b, hipMemcpyHostToDevice)); }
+  void get(void* d, const void* s, size_t b) override { if (b) HIP_OK(hipMemcpy(d, s, b, hipMemcpyDeviceToHost)); }
+  void copy(void* d, const void* s, size_t b) override { if (b) HIP_OK(hipMemcpy(d, s, b, hipMemcpyDeviceToDevice)); }
+  void fill_ff(void* d, size_t b) override { if (b) { HIP_OK(hipMemset(d, 0xff, b)); HIP_OK(hipDeviceSynchronize()); } }
+  void all_reduce_max_f32(float* buf, size_t n) override
+  {
+    std::vector<float> mine(n), all(n * (size_t)world());
+    get(mine.data(), buf, n * sizeof(float));
+    exchange(mine.data(), all.data(), n * sizeof(float));
+    for (size_t i = 0; i < n; ++i)
+      for (int k = 0; k < world(); ++k) mine[i] = std::max(mine[i], all[(size_t)k * n + i]);
+    put(buf, mine.data(), n * sizeof(float));
+  }
+  void all_reduce_sum_i64(int64_t* buf, size_t n) override
+  {
+    std::vector<int64_t> mine(n), all(n * (size_t)world());
+    get(mine.data(), buf, n * sizeof(int64_t));
+    exchange(mine.data(), all.data(), n * sizeof(int64_t));
+    for (size_t i = 0; i < n; ++i) {
+      int64_t t = 0;
+      for (int k = 0; k < world(); ++k) t += all[(size_t)k * n + i];
+      mine[i] = t;
+    }
+    put(buf, mine.data(), n * sizeof(int64_t));
+  }
+  void all_gather_v(const void* send, void* recv, const std::vector<size_t>& bytes) override
+  {
+    g_.ptr()[rank_] = send;
+    g_.barrier();
+    size_t at = 0;
+    for (int k = 0; k < world(); ++k) {
+      copy(static_cast<char*>(recv) + at, g_.ptr()[k], bytes[k]);
+      at += bytes[k];
+    }
+    g_.barrier();
+  }
+  void all_to_all_v(const float* send, const std::vector<int64_t>& sc, float* recv, const std::vector<int64_t>& rc) override
+  {
+    g_.ptr()[rank_] = send;
+    g_.cnt()[rank_] = sc.data();
+    g_.barrier();
+    size_t at = 0;
+    for (int s = 0; s < world(); ++s) {
+      const int64_t* c = g_.cnt()[s];
+      size_t off = 0;
+      for (int d = 0; d < rank_; ++d) off += (size_t)c[d];
+      copy(recv + at, static_cast<const float*>(g_.ptr()[s]) + off, sizeof(float) * (size_t)rc[s]);
+      at += (size_t)rc[s];
+    }
+    g_.barrier();
+  }
+
+ private:
+  void exchange(const void* mine, void* all, size_t bytes)  // host buffers: every rank's `mine`, in rank order
+  {
+    g_.ptr()[rank_] = mine;
+    g_.barrier();
+    for (int k = 0; k < world(); ++k) std::memcpy(static_cast<char*>(all) + (size_t)k * bytes, g_.ptr()[k], bytes);
+    g_.barrier();
+  }
+  ThreadGroup& g_;
+  int rank_;
+};
+
 }  // namespace
+
+int run_cloud_as_ranks_on_gpu0(int n_ranks, const hope_config& cfg, const float* xyz_host, size_t n, int apply,
+                               MultiResult& out, std::string& err)
+{
+  if (n_ranks < 1 || n_ranks > 8) {
+    err = "run_cloud_as_ranks_on_gpu0: 1 to 8 ranks";
+    return HOPE_E_INVALID;
+  }
+  ThreadGroup group(n_ranks);
+  std::vector<int> status((size_t)n_ranks, 0);
+  std::vector<std::string> errs((size_t)n_ranks);
+  std::vector<MultiResult> results((size_t)n_ranks);
+  std::vector<hope_ctx*> ctxs((size_t)n_ranks, nullptr);
+  for (int r = 0; r < n_ranks; ++r) {  // (created up front: a rank that cannot start would leave the others waiting)
+    hope_config c = cfg;
+    c.device = 0;
+    if (hope_create(&c, &ctxs[r]) != HOPE_OK) {
+      for (hope_ctx* x : ctxs) if (x) hope_destroy(x);
+      err = "hope_create failed";
+      return HOPE_E_HIP;
+    }
+  }
+  std::vector<std::thread> threads;
+  for (int r = 0; r < n_ranks; ++r)
+    threads.emplace_back([&, r] {
+      try {
+        HIP_OK(hipSetDevice(0));
+        DeviceThreadComm comm(group, r);
+        const size_t lo = n * (size_t)r / (size_t)n_ranks, hi = n * (size_t)(r + 1) / (size_t)n_ranks;
+        status[r] = segment_cloud_multi(ctxs[r], comm, xyz_host + 3 * lo, hi - lo, apply, cfg, results[r], errs[r]);
+      } catch (const std::exception& e) {
+        status[r] = HOPE_E_INVALID;
+        errs[r] = e.what();
+      }
+    });
+  for (std::thread& t : threads) t.join();
+  for (hope_ctx* x : ctxs) hope_destroy(x);
+  for (int r = 0; r < n_ranks; ++r)
+    if (status[r] < 0) {
+      err = "rank " + std::to_string(r) + ": " + errs[r];
+      return status[r];
+    }
+  out = std::move(results[0]);
+  return status[0];
+}
 
 int run_cloud_on_gpus(int n_gpus, const hope_config& cfg, const float* xyz_host, size_t n, int apply,
                       const float* t_xyz, const float* q_xyzw, MultiResult& out, std::string& err)

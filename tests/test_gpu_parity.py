@@ -912,3 +912,39 @@ def test_hope_node_over_rccl(oracle_lib, tmp_path, monkeypatch):
     planes = [k for k in c.clusters(0) if k["pass"] == 1]
     assert len(planes) >= 4
     check_record(recs[0], c.counts(0), planes)
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_hope_node_ranks_on_one_gpu(oracle_lib, tmp_path, monkeypatch, ranks):
+    """The C++ orchestration with MORE than one rank on the card: HOPE_NODE_RANKS_ON_GPU0=N runs N ranks as threads,
+    each with its own ctx and device buffers on device 0, collectives as device copies (rccl_comm.cpp
+    DeviceThreadComm).  Everything of the multi-rank path but the RCCL transport runs on the HIP library: the staged
+    entry points with device pointers, the routed all-to-all, the z bands.  Records == the oracle's on the whole
+    cloud."""
+    from test_host_cpu import check_record, run_node
+    from test_sharding_cpu import _layer_cloud
+    node = os.path.join(ROOT, "hope_amd", "host", "hope_node")
+    xyz = _layer_cloud()
+    p = tmp_path / "layers.ply"
+    p.write_bytes(("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+                   "end_header\n" % len(xyz)).encode() + xyz.tobytes())
+    monkeypatch.setenv("HOPE_NODE_RANKS_ON_GPU0", str(ranks))
+    r, recs = run_node(node, [p, "ply"], tmp_path, hull=False)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert recs[0]["gpus"] == ranks and recs[0]["path"] == "z-bands", recs[0]
+    c = HopeContext(oracle_lib)
+    c.segment_cloud(xyz, apply_filter_transform=False)
+    planes = [k for k in c.clusters(0) if k["pass"] == 1]
+    assert len(planes) >= 4
+    check_record(recs[0], c.counts(0), planes)
+    if ranks == 2:   # a ramp has no empty layer to cut at: the replicated fallback, also on device buffers
+        from test_sharding_cpu import _ramp_cloud
+        xyz = _ramp_cloud()
+        p.write_bytes(("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+                       "end_header\n" % len(xyz)).encode() + xyz.tobytes())
+        r, recs = run_node(node, [p, "ply"], tmp_path, hull=False)
+        assert r.returncode == 0, r.stderr + r.stdout
+        assert recs[0]["path"] == "replicated", recs[0]
+        c = HopeContext(oracle_lib)
+        c.segment_cloud(xyz, apply_filter_transform=False)
+        check_record(recs[0], c.counts(0), [k for k in c.clusters(0) if k["pass"] == 1])
