@@ -7,6 +7,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1019,8 +1020,15 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
     prof_close(c, ST_SEGMENTS, pm, (4.0 + 4.0 + 2 * 8.0 + 2 * 8.0) * n_fit);
     pm = prof_mark(c);
     // ---- A10..A12 -------------------------------------------------------------------
-    hipLaunchKernelGGL(k_cluster_verify_b, dim3(n_cl), dim3(kBlock), 0, s, members, cl_first, fit_pt, fit_nrm, n_cl,
-                       c->th_angle, rec);
+    // a cluster holds points of one frame, so max_fit bounds its size: depth batches never take the second launch.
+    // A floor or a wall gets longer tiles (more LDS per workgroup, so for these alone); running the two launches
+    // side by side on two streams was measured and gains nothing over one after the other
+    const bool big = max_fit >= (unsigned)kVBigFrom;
+    hipLaunchKernelGGL(k_cluster_verify_b<kVTile>, dim3(n_cl), dim3(kBlock), 0, s, members, cl_first, fit_pt, fit_nrm,
+                       n_cl, c->th_angle, 0, big ? kVBigFrom : INT_MAX, rec);
+    if (big)
+      hipLaunchKernelGGL(k_cluster_verify_b<kVTileBig>, dim3(n_cl), dim3(kBlock), 0, s, members, cl_first, fit_pt,
+                         fit_nrm, n_cl, c->th_angle, kVBigFrom, INT_MAX, rec);
     prof_close(c, ST_VERIFY, pm, (4.0 + 16.0 + 16.0) * n_fit + 32.0 * n_cl);
     c->h_rec.resize(n_cl);
     HIPCHK(hipMemcpyAsync(c->h_rec.data(), rec, sizeof(ClusterRec) * n_cl, hipMemcpyDeviceToHost, s));

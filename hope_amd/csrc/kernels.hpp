@@ -1902,10 +1902,10 @@ __device__ inline void principal_axis_2x2(float a, float b, float d, float& ax, 
 // instead of a memory round trip, which matters for the one huge cluster (a floor) that bounds
 // the kernel.  Terms that the reference skips (a non-finite z, the other side of the split)
 // enter as +0.0f, which leaves a running sum that started at +0.0f bit-identical.
-constexpr int kVTile = 384;                    // members per tile
-constexpr int kVLoaders = kBlock - kWave;         // 192 loader threads
-constexpr int kVPer = kVTile / kVLoaders;         // 6 members per loader thread per tile
-constexpr int kVStride = kVTile + 4;              // LDS row stride: the 6 chain lanes hit different banks
+constexpr int kVTile = 384;                    // members per tile ...
+constexpr int kVTileBig = 1152;                // ... and for the clusters of kVBigFrom members and more: a tile costs
+constexpr int kVBigFrom = 32768;               // ~0.25 us of barrier and pipeline fill on top of its adds (measured)
+constexpr int kVLoaders = kBlock - kWave;      // 192 loader threads (2 or 6 members each per tile)
 
 // acc + sv[0] + sv[1] + ... in that order.  The adds are one dependent chain (4 cycles each); the LDS
 // reads that feed it are issued a whole block (32 values, 8 x 16 bytes) ahead, so the chain never waits
@@ -1964,10 +1964,12 @@ __device__ __forceinline__ float chain_sum(const float* sv, int n, float acc)
 
 // One pass over the members: loaders call term(point, normal, slot) for every member of a tile,
 // wave 0 sums rows 0..n_chains-1 of the tile in member order.  Returns this lane's chain sum.
-template <bool NEED_POINT, class Term>
+template <int kVTile, bool NEED_POINT, class Term>
 __device__ __forceinline__ float verify_pass(const uint32_t* m, int sz, const float4* fit_pt, const float4* fit_nrm,
-                                             float (*s_v)[6][kVStride], int n_chains, Term&& term)
+                                             float (*s_v)[6][kVTile + 4], int n_chains, Term&& term)
 {
+  constexpr int kVPer = kVTile / kVLoaders;
+  static_assert(kVTile % kVLoaders == 0 && kVTile % 32 == 0, "whole loader rounds, whole chain blocks");
   const int tid = threadIdx.x;
   const bool loader = tid >= kWave;
   const int lt = tid - kWave;
@@ -2046,10 +2048,12 @@ __device__ __forceinline__ unsigned block_sum_u32(unsigned v, unsigned* s_cnt)
   return r;
 }
 
+template <int kVTile>
 __global__ void __launch_bounds__(kBlock)
 k_cluster_verify_b(const uint32_t* members, const uint32_t* cl_first, const float4* fit_pt, const float4* fit_nrm,
-                   unsigned n_cl, float th_angle, ClusterRec* rec)
+                   unsigned n_cl, float th_angle, int size_from, int size_below, ClusterRec* rec)
 {
+  constexpr int kVStride = kVTile + 4;  // LDS row stride: the 6 chain lanes hit different banks
   __shared__ __attribute__((aligned(16))) float s_v[2][6][kVStride];
   __shared__ float s_bc[8];
   __shared__ float s_red[kBlock / kWave];
@@ -2061,11 +2065,12 @@ k_cluster_verify_b(const uint32_t* members, const uint32_t* cl_first, const floa
   const bool chain_wave = tid < kWave;
   const uint32_t* m = members + cl_first[c];
   const int sz = rec[c].size;
+  if (sz < size_from || sz >= size_below) return;  // (the launch with the other tile size has this cluster)
 
   // ---- pass 1: sum z (lane 0), sum nx, ny, |nz| (lanes 1..3); bbox + finite count by the loaders --
   unsigned ct = 0;
   float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
-  float acc = verify_pass<true>(m, sz, fit_pt, fit_nrm, s_v, 4, [&](const float4& p, const float4& nn, float* slot) {
+  float acc = verify_pass<kVTile, true>(m, sz, fit_pt, fit_nrm, s_v, 4, [&](const float4& p, const float4& nn, float* slot) {
     const bool fin = isfinite(p.z);
     slot[0 * kVStride] = fin ? p.z : 0.f;
     slot[1 * kVStride] = nn.x;
@@ -2097,7 +2102,7 @@ k_cluster_verify_b(const uint32_t* members, const uint32_t* cl_first, const floa
     if (!(grad > th_angle)) {  // block-uniform
       // ---- pass 2: covariance sums cxx, cxy, cyy (lanes 0..2) ---------------------------------
       const float cacc =
-          verify_pass<false>(m, sz, fit_pt, fit_nrm, s_v, 3, [&](const float4&, const float4& nn, float* slot) {
+          verify_pass<kVTile, false>(m, sz, fit_pt, fit_nrm, s_v, 3, [&](const float4&, const float4& nn, float* slot) {
             const float tx = nn.x - m0, ty = nn.y - m1;
             slot[0 * kVStride] = tx * tx;
             slot[1 * kVStride] = tx * ty;
@@ -2115,7 +2120,7 @@ k_cluster_verify_b(const uint32_t* members, const uint32_t* cl_first, const floa
       // ---- pass 3: split sums; lanes 0..2 own part 1 (nx, ny, |nz|), lanes 3..5 part 2 ----------
       unsigned na = 0;
       const float pacc =
-          verify_pass<false>(m, sz, fit_pt, fit_nrm, s_v, 6, [&](const float4&, const float4& nn, float* slot) {
+          verify_pass<kVTile, false>(m, sz, fit_pt, fit_nrm, s_v, 6, [&](const float4&, const float4& nn, float* slot) {
             const float tx = nn.x - m0, ty = nn.y - m1;
             const bool side = (ax * tx + ay * ty > 0.f);
             const float nz = fabsf(nn.z);

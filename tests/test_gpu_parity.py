@@ -143,6 +143,13 @@ def test_one_huge_cluster(hip_lib, oracle_lib):
         assert c.segment_cloud(xyz) == 0
     assert_frame_equal(o, g, 0)
     assert g.clusters(0)["size"].max() > 16384
+    # 14 m x 14 m: past kVBigFrom = 32768 members, where the launch with the longer tiles takes the cluster over
+    n = 1200000
+    xyz = np.concatenate([rng.uniform(-7, 7, (n, 2)), rng.normal(0.0, 0.002, (n, 1))], 1).astype(np.float32)
+    for c in (g, o):
+        assert c.segment_cloud(xyz) == 0
+    assert_frame_equal(o, g, 0)
+    assert g.clusters(0)["size"].max() > 40000 and g.counts(0).n_planes >= 1
 
 
 def test_rt_mode_and_height_window(hip_lib, oracle_lib):
