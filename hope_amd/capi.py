@@ -92,6 +92,14 @@ class HopeLib:
                 "or make -C hope_amd/csrc). There is no CPU fallback.")
         self.path = path
         self.prefix = prefix
+        if prefix == "hope_":
+            # A PyTorch-ROCm wheel brings a HIP runtime of its own, and a process has to stay with ONE runtime: when the
+            # library is loaded first it pulls in /opt/rocm's, and a later `import torch` then finds "No HIP GPUs".
+            # Torch first, and the library binds to the runtime that is already there.  (C/C++ hosts link /opt/rocm.)
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         self.dll = C.CDLL(path, mode=C.RTLD_LOCAL)
         vp, i32, f32p = C.c_void_p, C.c_int, C.POINTER(C.c_float)
         sig = {

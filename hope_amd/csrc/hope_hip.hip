@@ -199,6 +199,8 @@ struct hope_ctx {
   int col_sort_z = 0;         // test knob HOPE_DEBUG_COLSORT_Z=1: z cell bits in the column sort key even for VoxelGrid output
   int seg_sort = 1;           // per-frame segmented sort of the group records (HOPE_DEBUG_SEGSORT=0: device-wide sort)
   int col_index_lds = 1;      // column index by a per-frame counting sort in LDS when the tables fit (HOPE_DEBUG_COL_INDEX=0: the radix sort)
+  int knn_direct = 1;         // A6 and A8 read the column index straight from HBM through the caches, one thread per
+  int normals_direct = 1;     // point (k_normals_direct, k_knn_direct); HOPE_DEBUG_NEIGHBOURS=tiles: the LDS tile kernels
   int tile_side = 0;          // neighbour tiles: 0 = chosen per call from the points per super tile; HOPE_DEBUG_TILE_SIDE=16|32 forces
   int voxel_rank = 1;         // depth batches: voxels ranked by an LDS bitmap per frame instead of sorting the group
                               // records (HOPE_DEBUG_VOXEL_RANK=0, or any knob that asks for a sort: the sorting path)
@@ -771,6 +773,15 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   if (c->inj_normals) {
     HIPCHK(hipMemcpyAsync(d_normals, c->inj_normals, sizeof(float4) * (size_t)n_vox,
                           c->inj_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+  } else if (c->normals_direct) {
+    const int* vf = F == 1 ? nullptr : d_vox_frame;
+    if (c->normals_cap_small)
+      hipLaunchKernelGGL((k_normals_direct<2>), dim3(nblk(n_vox)), dim3(kBlock), 0, s, spt, col_first, c->d_fi, c->inv_xy,
+                         c->inv_z, c->radius, c->r2, c->ring, c->own_lo, c->own_hi, (unsigned)n_vox, vf, d_normals);
+    else
+      hipLaunchKernelGGL((k_normals_direct<kNbCap>), dim3(nblk(n_vox)), dim3(kBlock), 0, s, spt, col_first, c->d_fi,
+                         c->inv_xy, c->inv_z, c->radius, c->r2, c->ring, c->own_lo, c->own_hi, (unsigned)n_vox, vf,
+                         d_normals);
   } else {
 #define HOPE_NORMALS(CAP, SIDE)                                                                                       \
   hipLaunchKernelGGL((k_normals_tile<CAP, SIDE>), tile_grid, dim3(kBlock), 0, s, spt, col_first, c->d_fi, c->inv_xy, \
@@ -849,6 +860,16 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   if (c->inj_knn) {
     HIPCHK(hipMemcpyAsync(knn, c->inj_knn, sizeof(int) * (size_t)n_fit * K,
                           c->inj_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+  } else if (c->knn_direct) {
+    const int* ff = F == 1 ? nullptr : fit_frame;
+    if (K <= 8)
+      hipLaunchKernelGGL((k_knn_direct<8>), dim3(nblk(n_fit)), dim3(kBlock), 0, s, spt_fit, col_first_fit, c->d_fi, ff,
+                         c->inv_xy, c->inv_z, c->cfg.th_xy, K, fit_idx, c->own_lo, c->own_hi, n_fit, knn, todo,
+                         &c->d_glob->n_todo);
+    else
+      hipLaunchKernelGGL((k_knn_direct<kMaxKnn>), dim3(nblk(n_fit)), dim3(kBlock), 0, s, spt_fit, col_first_fit, c->d_fi,
+                         ff, c->inv_xy, c->inv_z, c->cfg.th_xy, K, fit_idx, c->own_lo, c->own_hi, n_fit, knn, todo,
+                         &c->d_glob->n_todo);
   } else {
     const int side_k = c->tile_side ? c->tile_side : tile_side(n_fit);
 #define HOPE_KNN(KL, SIDE)                                                                                              \
@@ -1321,6 +1342,11 @@ HOPE_API int hope_create(const hope_config* cfg, hope_ctx** out)
   c->col_index_lds = (knob && knob[0] == '0') ? 0 : 1;
   knob = std::getenv("HOPE_DEBUG_TILE_SIDE");
   if (knob) c->tile_side = std::atoi(knob) == kSuper ? kSuper : (std::atoi(knob) == kTile ? kTile : 0);
+  knob = std::getenv("HOPE_DEBUG_NEIGHBOURS");  // tiles | tiles-normals | tiles-knn
+  if (knob && std::strncmp(knob, "tiles", 5) == 0) {
+    c->normals_direct = std::strcmp(knob, "tiles-knn") == 0 ? 1 : 0;
+    c->knn_direct = std::strcmp(knob, "tiles-normals") == 0 ? 1 : 0;
+  }
   knob = std::getenv("HOPE_DEBUG_VOXEL_RANK");
   c->voxel_rank = (knob && knob[0] == '0') ? 0 : c->seg_sort;
   *out = c;

@@ -56,9 +56,15 @@ struct GlobalColsT {  // a column index straight from HBM: W_IS_RANK false = eve
     return W_IS_RANK ? __float_as_int(p.w) : fit_rank[__float_as_uint(p.w)];
   }
   static constexpr bool kLds = false;
+  static constexpr bool kNotes = false;  // A6 re-scans the stencil for every pick instead of noting the neighbours
+  typedef unsigned short cand_t;
 };
 typedef GlobalColsT<false> GlobalCols;
 typedef GlobalColsT<true> CoarseCols;
+struct GlobalColsNotes : GlobalCols {  // ... or notes them as 32-bit positions in the sorted array (k_normals_direct)
+  static constexpr bool kNotes = true;
+  typedef unsigned cand_t;
+};
 
 template <int HALO>
 struct TileCols {  // LDS copy of a tile and its halo
@@ -81,6 +87,8 @@ struct TileCols {  // LDS copy of a tile and its halo
   __device__ __forceinline__ float4 pt(unsigned e) const { return s_pt[e]; }
   __device__ __forceinline__ int fit(unsigned, const float4& p) const { return __float_as_int(p.w); }
   static constexpr bool kLds = true;
+  static constexpr bool kNotes = true;
+  typedef unsigned short cand_t;
 };
 
 template <bool WITH_FIT, int HALO>
@@ -694,7 +702,7 @@ __device__ __forceinline__ void accumulate_by_rescan(const Cols& cols, const flo
   }
 
 template <class Cols, int N>
-__device__ __forceinline__ void accumulate_sorted(const Cols& cols, const float4 q, const unsigned short* cand_e,
+__device__ __forceinline__ void accumulate_sorted(const Cols& cols, const float4 q, const typename Cols::cand_t* cand_e,
                                                   int total, float* accu)
 {
   static_assert(N == 8 || N == 12 || N == 16 || N == 32, "sorting networks exist for 8, 12, 16 and 32 inputs");
@@ -729,7 +737,7 @@ __device__ __forceinline__ void accumulate_sorted(const Cols& cols, const float4
 template <class Cols, int CAPL>
 __device__ __forceinline__ float4 estimate_normal(const Cols& cols, const float4 q, int cqx, int cqy, int dx, int dy,
                                                   int ring, float radius, float r2, float leaf_z,
-                                                  unsigned short* cand_e, int ablate = 0)
+                                                  typename Cols::cand_t* cand_e, int ablate = 0)
 {
   static_assert(CAPL <= kNbCap, "the largest sorting network has kNbCap inputs");
   const int x0 = max(cqx - ring, 0), x1 = min(cqx + ring, dx - 1);
@@ -739,7 +747,7 @@ __device__ __forceinline__ float4 estimate_normal(const Cols& cols, const float4
   for (int cy = y0; cy <= y1; ++cy) {
     for_window(cols, x0, x1, cy, zlo, zhi, [&](unsigned e, const float4& p) {
       if (dist2(q.x, q.y, q.z, p.x, p.y, p.z) < r2) {
-        if (Cols::kLds && total < CAPL) cand_e[total * kBlock] = (unsigned short)e;
+        if (Cols::kNotes && total < CAPL) cand_e[total * kBlock] = (typename Cols::cand_t)e;
         ++total;
       }
     });
@@ -747,7 +755,7 @@ __device__ __forceinline__ float4 estimate_normal(const Cols& cols, const float4
   if (total < 3) return make_float4(NAN, NAN, NAN, NAN);
   if (ablate == 2) return make_float4((float)total, 0.f, 0.f, 0.f);
   float accu[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (Cols::kLds && total <= CAPL) {
+  if (Cols::kNotes && total <= CAPL) {
     // wave-uniform choice of the network: the smallest one that holds the longest list of the wave (a horizontal
     // surface finds 5..10 neighbours)
     if (CAPL <= 8 || !__any(total > 8))
@@ -828,6 +836,37 @@ k_normals_tile(const float4* spt, const uint32_t* col_first, const FrameInfo* fi
               estimate_normal<GlobalCols, CAPL>(gc, q, cqx, cqy, dx, dy, ring, radius, r2, leaf_z, cand_e, ablate);
         });
   }
+}
+
+// A6 without tiles, for ONE cloud whose columns are tall (walls, shelves, clutter: most of a tile copy would be
+// halo in z): one thread per point in column order, the stencil read straight from the sorted array.  The lanes of
+// a wave are neighbours in a column or in adjacent columns, so their scans read the same cache lines.
+// (4 waves per SIMD at 128 VGPRs and 44 bytes of spills beat 3 at 135 and none: 1.29 against 1.52 ms on the frame
+// batch; 5 at 96 VGPRs lose again)
+template <int CAPL>
+__global__ void __launch_bounds__(kBlock, 4)
+k_normals_direct(const float4* spt, const uint32_t* col_first, const FrameInfo* fi, float inv_xy, float inv_z,
+                 float radius, float r2, int ring, unsigned own_lo, unsigned own_hi, unsigned n, const int* vox_frame,
+                 float4* normals)
+{
+  __shared__ unsigned s_cand[CAPL * kBlock];
+  const unsigned e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= n) return;
+  const float4 q = spt[e];
+  const unsigned idx = __float_as_uint(q.w);
+  if (idx < own_lo || idx >= own_hi) return;  // (staged multi-GPU call: another rank's point)
+  const FrameInfo& F = fi[vox_frame ? vox_frame[idx] : 0];
+  const int dx = F.div_b[0], dy = F.div_b[1];
+  const int cqx = clampi(cell_unclamped(q.x, inv_xy, F.min_b[0]), 0, dx - 1);
+  const int cqy = clampi(cell_unclamped(q.y, inv_xy, F.min_b[1]), 0, dy - 1);
+  GlobalColsNotes gc;
+  gc.spt = spt;
+  gc.col_first = col_first;
+  gc.fit_rank = nullptr;
+  gc.col_off = (unsigned)F.col_off;
+  gc.dx = dx;
+  normals[idx] = estimate_normal<GlobalColsNotes, CAPL>(gc, q, cqx, cqy, dx, dy, ring, radius, r2, 1.0f / inv_z,
+                                                        s_cand + threadIdx.x);
 }
 
 // ---- A8: exact k nearest neighbours among the fit points ---------------------------------------
@@ -1011,6 +1050,73 @@ k_knn_tile(const float4* spt, const uint32_t* col_first, const int* fit_rank, co
       if (!done) todo[atomicAdd(n_todo, 1u)] = (uint32_t)me | (g.slab ? kTodoFromRing0 : 0u);
     }, leftover);
   }
+}
+
+// Phase A without tiles: one thread per fit point in column order, the columns read straight from the column index
+// of the fit points (.w = fit rank).  Same fast pass, same ring expansion up to kHaloKnn, same leftovers as
+// k_knn_tile; the lanes of a wave are neighbours on a surface, so their scans share cache lines.
+// (K <= 8: 5 waves per SIMD at 96 VGPRs; 6 at 80 spill too much: 2.4 against 1.33 ms)
+template <int KMAX>
+__global__ void __launch_bounds__(kBlock, KMAX <= 8 ? 5 : 1)
+k_knn_direct(const float4* spt_fit, const uint32_t* col_first_fit, const FrameInfo* fi, const int* fit_frame,
+             float inv_xy, float inv_z, float cell_xy, int K, const uint32_t* fit_idx, unsigned own_lo, unsigned own_hi,
+             unsigned n_fit, int* knn_out, uint32_t* todo, unsigned* n_todo)
+{
+  const unsigned e0 = blockIdx.x * kBlock + threadIdx.x;
+  if (e0 >= n_fit) return;
+  const float4 q = spt_fit[e0];
+  const int me = __float_as_int(q.w);
+  if (own_hi - own_lo != 0xffffffffu) {  // staged multi-GPU call: only this rank's share of the queries
+    const unsigned idx = fit_idx[me];
+    if (idx < own_lo || idx >= own_hi) return;
+  }
+  const FrameInfo& F = fi[fit_frame ? fit_frame[me] : 0];
+  const int dx = F.div_b[0], dy = F.div_b[1];
+  const int cqx = clampi(cell_unclamped(q.x, inv_xy, F.min_b[0]), 0, dx - 1);
+  const int cqy = clampi(cell_unclamped(q.y, inv_xy, F.min_b[1]), 0, dy - 1);
+  const float leaf_z = 1.0f / inv_z;
+  const int k = min(K, F.n_fit);
+  const float reach2 = ring_reach(2, F.slack, cell_xy);
+  const float zwin = reach2 + 1.5f * leaf_z;
+  const CoarseCols tc{spt_fit, col_first_fit, nullptr, (unsigned)F.col_off, dx};
+  knn_key lst[KMAX];
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) lst[j] = kKnnEmpty;
+  const int max_ring = max(max(cqx, dx - 1 - cqx), max(cqy, dy - 1 - cqy));
+  bool done = false;
+  if (reach2 > 0.f) {
+    const int x0 = max(cqx - 2, 0), x1 = min(cqx + 2, dx - 1);
+    const float zlo = q.z - zwin, zhi = q.z + zwin;
+    auto offer = [&](unsigned e, const float4& p) { knn_offer<CoarseCols, KMAX>(tc, q, e, p, k, lst); };
+    const int xc0 = max(cqx - 1, 0), xc1 = min(cqx + 1, dx - 1);
+#pragma unroll 1
+    for (int s = 0; s < 3; ++s) {
+      const int cy = cqy + (s == 0 ? 0 : (s == 1 ? -1 : 1));
+      if (cy < 0 || cy >= dy) continue;
+      for_window(tc, xc0, xc1, cy, zlo, zhi, offer);
+    }
+#pragma unroll 1
+    for (int s = 0; s < 5; ++s) {
+      const int cy = cqy + s - 2;
+      if (cy < 0 || cy >= dy) continue;
+      if (s == 0 || s == 4) {
+        for_window(tc, x0, x1, cy, zlo, zhi, offer);
+      } else {
+        if (cqx - 2 >= 0) for_window(tc, cqx - 2, cqx - 2, cy, zlo, zhi, offer);
+        if (cqx + 2 < dx) for_window(tc, cqx + 2, cqx + 2, cy, zlo, zhi, offer);
+      }
+    }
+    done = knn_kth<KMAX>(k, lst) < reach2 * reach2 * 0.999999f;
+  }
+  if (!done) {
+    done = knn_rings<CoarseCols, KMAX, true>(tc, q, cqx, cqy, dx, dy, 0, min(kHaloKnn, max_ring), k, F.slack, cell_xy,
+                                             leaf_z, lst);
+    if (max_ring <= kHaloKnn) done = true;  // every column of the frame has been visited
+  }
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j)
+    if (j < K) knn_out[(size_t)me * K + j] = (j < k) ? (int)(unsigned)lst[j] : -1;
+  if (!done) todo[atomicAdd(n_todo, 1u)] = (uint32_t)me;
 }
 
 // Phase B: the queries of `todo`, one WAVE each, by ring expansion over a whole-frame column

@@ -292,8 +292,10 @@ def test_group_records_through_the_segmented_sort(hip_lib, oracle_lib, monkeypat
 
 
 def test_neighbour_tile_side(hip_lib, oracle_lib, monkeypatch):
-    """The neighbour kernels give a workgroup a 32x32-column super tile (sparse frames) or one 16x16 tile (dense
-    clouds); the library picks per call from the points per super tile, the knob forces either.  Same bits."""
+    """The second implementation of A6 / A8 (HOPE_DEBUG_NEIGHBOURS=tiles: LDS copies of column tiles instead of the
+    direct reads of the default kernels) gives a workgroup a 32x32-column super tile (sparse frames) or one 16x16 tile
+    (dense clouds), picked per call from the points per super tile; the knob forces either.  Same bits."""
+    monkeypatch.setenv("HOPE_DEBUG_NEIGHBOURS", "tiles")
     from hope_amd import synth
     depth, t, q = synth_frames(2, first=61)
     xyz = synth.make_multilevel_cloud(200000, first_index=99, device="cpu").numpy()
@@ -311,6 +313,34 @@ def test_neighbour_tile_side(hip_lib, oracle_lib, monkeypatch):
             assert_frame_equal(o, g, f)
         g.segment_cloud(xyz)
         assert_frame_equal(oc, g, 0)
+
+
+def test_neighbour_kernels_direct_or_tiles(hip_lib, oracle_lib, monkeypatch):
+    """A6 and A8 by the default kernels (one thread per point, the column index read through the caches) and by the
+    LDS tile kernels, each alone and both: 16 frames, a multi-level scene and the loft fixture, all == the oracle."""
+    from hope_amd import synth
+    depth, t, q = synth_frames(16, first=200)
+    clouds = [synth.make_multilevel_cloud(400000, first_index=777, device="cpu").numpy(),
+              np.load(os.path.join(GOLDEN, "loft_120k.npz"))["xyz"]]
+    o = HopeContext(oracle_lib)
+    o.set_frame_poses(t, q)
+    o.segment_depth(depth)
+    want_frames = [summary(o, f) for f in range(16)]
+    want_clouds = []
+    for xyz in clouds:
+        o.segment_cloud(xyz)
+        want_clouds.append(summary(o, 0))
+    for mode in (None, "tiles", "tiles-normals", "tiles-knn"):
+        if mode:
+            monkeypatch.setenv("HOPE_DEBUG_NEIGHBOURS", mode)
+        g = HopeContext(hip_lib)
+        monkeypatch.delenv("HOPE_DEBUG_NEIGHBOURS", raising=False)
+        g.set_frame_poses(t, q)
+        g.segment_depth(depth)
+        assert [summary(g, f) for f in range(16)] == want_frames, mode
+        for xyz, want in zip(clouds, want_clouds):
+            g.segment_cloud(xyz)
+            assert summary(g, 0) == want, mode
 
 
 def test_count_read_backs_by_mailbox_or_copy(hip_lib, oracle_lib, monkeypatch):
