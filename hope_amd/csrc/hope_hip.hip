@@ -199,6 +199,7 @@ struct hope_ctx {
   int col_sort_z = 0;         // test knob HOPE_DEBUG_COLSORT_Z=1: z cell bits in the column sort key even for VoxelGrid output
   int seg_sort = 1;           // per-frame segmented sort of the group records (HOPE_DEBUG_SEGSORT=0: device-wide sort)
   int col_index_lds = 1;      // column index by a per-frame counting sort in LDS when the tables fit (HOPE_DEBUG_COL_INDEX=0: the radix sort)
+  int todo_threads = 1;       // HOPE_DEBUG_TODO_THREADS=0: the k-NN leftovers over the coarse index by a wave each
   int knn_direct = 1;         // A6 and A8 read the column index straight from HBM through the caches, one thread per
   int normals_direct = 1;     // point (k_normals_direct, k_knn_direct); HOPE_DEBUG_NEIGHBOURS=tiles: the LDS tile kernels
   int tile_side = 0;          // neighbour tiles: 0 = chosen per call from the points per super tile; HOPE_DEBUG_TILE_SIDE=16|32 forces
@@ -926,7 +927,11 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
       hipLaunchKernelGGL((k_column_table<CK>), dim3(nblk((size_t)n_fit + 1)), dim3(kBlock), 0, s, qk_out, n_fit,
                          total_ccols, zbits, ccol_first);
       hipLaunchKernelGGL(k_gather_coarse, dim3(nblk(n_fit)), dim3(kBlock), 0, s, fit_pt, qv_out, n_fit, cspt);
-      if (K <= 8)
+      if (K <= 8 && c->todo_threads)  // many queries: a thread each
+        hipLaunchKernelGGL((k_knn_todo_threads<8>), dim3(nblk(n_todo)), dim3(kBlock), 0, s, todo, &c->d_glob->n_todo,
+                           fit_pt, fit_frame, cspt, ccol_first, c->d_fi, c->inv_xy, c->inv_z, c->cfg.th_xy, kCoarse, K,
+                           knn);
+      else if (K <= 8)
         hipLaunchKernelGGL((k_knn_todo<CoarseCols, 8>), dim3(gt), dim3(kBlock), 0, s, todo, &c->d_glob->n_todo, fit_pt,
                            fit_frame, cspt, ccol_first, nullptr, c->d_fi, c->inv_xy, c->inv_z, c->cfg.th_xy, kCoarse, K,
                            knn);
@@ -1342,6 +1347,8 @@ HOPE_API int hope_create(const hope_config* cfg, hope_ctx** out)
   c->col_index_lds = (knob && knob[0] == '0') ? 0 : 1;
   knob = std::getenv("HOPE_DEBUG_TILE_SIDE");
   if (knob) c->tile_side = std::atoi(knob) == kSuper ? kSuper : (std::atoi(knob) == kTile ? kTile : 0);
+  knob = std::getenv("HOPE_DEBUG_TODO_THREADS");
+  if (knob) c->todo_threads = std::atoi(knob);
   knob = std::getenv("HOPE_DEBUG_NEIGHBOURS");  // tiles | tiles-normals | tiles-knn
   if (knob && std::strncmp(knob, "tiles", 5) == 0) {
     c->normals_direct = std::strcmp(knob, "tiles-knn") == 0 ? 1 : 0;

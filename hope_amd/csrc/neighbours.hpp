@@ -1055,33 +1055,16 @@ k_knn_tile(const float4* spt, const uint32_t* col_first, const int* fit_rank, co
 // Phase A without tiles: one thread per fit point in column order, the columns read straight from the column index
 // of the fit points (.w = fit rank).  Same fast pass, same ring expansion up to kHaloKnn, same leftovers as
 // k_knn_tile; the lanes of a wave are neighbours on a surface, so their scans share cache lines.
-// (K <= 8: 5 waves per SIMD at 96 VGPRs; 6 at 80 spill too much: 2.4 against 1.33 ms)
-template <int KMAX>
-__global__ void __launch_bounds__(kBlock, KMAX <= 8 ? 5 : 1)
-k_knn_direct(const float4* spt_fit, const uint32_t* col_first_fit, const FrameInfo* fi, const int* fit_frame,
-             float inv_xy, float inv_z, float cell_xy, int K, const uint32_t* fit_idx, unsigned own_lo, unsigned own_hi,
-             unsigned n_fit, int* knn_out, uint32_t* todo, unsigned* n_todo)
+// the fast pass and the ring expansion of one query; FULL: k == KMAX, known at compile time (the list code then has
+// no selects on k)
+template <int KMAX, bool FULL>
+__device__ __forceinline__ bool knn_direct_query(const CoarseCols& tc, const float4 q, int cqx, int cqy, int dx, int dy,
+                                                 int k_any, float slack, float cell_xy, float leaf_z,
+                                                 knn_key (&lst)[KMAX])
 {
-  const unsigned e0 = blockIdx.x * kBlock + threadIdx.x;
-  if (e0 >= n_fit) return;
-  const float4 q = spt_fit[e0];
-  const int me = __float_as_int(q.w);
-  if (own_hi - own_lo != 0xffffffffu) {  // staged multi-GPU call: only this rank's share of the queries
-    const unsigned idx = fit_idx[me];
-    if (idx < own_lo || idx >= own_hi) return;
-  }
-  const FrameInfo& F = fi[fit_frame ? fit_frame[me] : 0];
-  const int dx = F.div_b[0], dy = F.div_b[1];
-  const int cqx = clampi(cell_unclamped(q.x, inv_xy, F.min_b[0]), 0, dx - 1);
-  const int cqy = clampi(cell_unclamped(q.y, inv_xy, F.min_b[1]), 0, dy - 1);
-  const float leaf_z = 1.0f / inv_z;
-  const int k = min(K, F.n_fit);
-  const float reach2 = ring_reach(2, F.slack, cell_xy);
+  const int k = FULL ? KMAX : k_any;
+  const float reach2 = ring_reach(2, slack, cell_xy);
   const float zwin = reach2 + 1.5f * leaf_z;
-  const CoarseCols tc{spt_fit, col_first_fit, nullptr, (unsigned)F.col_off, dx};
-  knn_key lst[KMAX];
-#pragma unroll
-  for (int j = 0; j < KMAX; ++j) lst[j] = kKnnEmpty;
   const int max_ring = max(max(cqx, dx - 1 - cqx), max(cqy, dy - 1 - cqy));
   bool done = false;
   if (reach2 > 0.f) {
@@ -1109,10 +1092,43 @@ k_knn_direct(const float4* spt_fit, const uint32_t* col_first_fit, const FrameIn
     done = knn_kth<KMAX>(k, lst) < reach2 * reach2 * 0.999999f;
   }
   if (!done) {
-    done = knn_rings<CoarseCols, KMAX, true>(tc, q, cqx, cqy, dx, dy, 0, min(kHaloKnn, max_ring), k, F.slack, cell_xy,
+    done = knn_rings<CoarseCols, KMAX, true>(tc, q, cqx, cqy, dx, dy, 0, min(kHaloKnn, max_ring), k, slack, cell_xy,
                                              leaf_z, lst);
     if (max_ring <= kHaloKnn) done = true;  // every column of the frame has been visited
   }
+  return done;
+}
+
+// (K <= 8: 5 waves per SIMD at 96 VGPRs; 6 at 80 spill too much: 2.4 against 1.33 ms)
+template <int KMAX>
+__global__ void __launch_bounds__(kBlock, KMAX <= 8 ? 5 : 1)
+k_knn_direct(const float4* spt_fit, const uint32_t* col_first_fit, const FrameInfo* fi, const int* fit_frame,
+             float inv_xy, float inv_z, float cell_xy, int K, const uint32_t* fit_idx, unsigned own_lo, unsigned own_hi,
+             unsigned n_fit, int* knn_out, uint32_t* todo, unsigned* n_todo)
+{
+  const unsigned e0 = blockIdx.x * kBlock + threadIdx.x;
+  if (e0 >= n_fit) return;
+  const float4 q = spt_fit[e0];
+  const int me = __float_as_int(q.w);
+  if (own_hi - own_lo != 0xffffffffu) {  // staged multi-GPU call: only this rank's share of the queries
+    const unsigned idx = fit_idx[me];
+    if (idx < own_lo || idx >= own_hi) return;
+  }
+  const FrameInfo& F = fi[fit_frame ? fit_frame[me] : 0];
+  const int dx = F.div_b[0], dy = F.div_b[1];
+  const int cqx = clampi(cell_unclamped(q.x, inv_xy, F.min_b[0]), 0, dx - 1);
+  const int cqy = clampi(cell_unclamped(q.y, inv_xy, F.min_b[1]), 0, dy - 1);
+  const float leaf_z = 1.0f / inv_z;
+  const int k = min(K, F.n_fit);
+  const CoarseCols tc{spt_fit, col_first_fit, nullptr, (unsigned)F.col_off, dx};
+  knn_key lst[KMAX];
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) lst[j] = kKnnEmpty;
+  bool done;
+  if (__all(k == KMAX))  // wave-uniform: the usual case (K = 8 and frames of more than 8 fit points)
+    done = knn_direct_query<KMAX, true>(tc, q, cqx, cqy, dx, dy, k, F.slack, cell_xy, leaf_z, lst);
+  else
+    done = knn_direct_query<KMAX, false>(tc, q, cqx, cqy, dx, dy, k, F.slack, cell_xy, leaf_z, lst);
 #pragma unroll
   for (int j = 0; j < KMAX; ++j)
     if (j < K) knn_out[(size_t)me * K + j] = (j < k) ? (int)(unsigned)lst[j] : -1;
@@ -1255,6 +1271,50 @@ k_knn_todo(const uint32_t* todo, const unsigned* n_todo, const float4* fit_pt, c
     for (int j = 0; j < KMAX; ++j)
       if (j < K) knn_out[(size_t)me * K + j] = (j < k) ? (int)(unsigned)lst[j] : -1;
   }
+}
+
+// Phase B for MANY queries (a scene full of clutter leaves 10^5 of them): one THREAD per query over the coarse
+// index, the rings one after the other (knn_rings, as in phase A).  A query then waits for every column of its rings
+// in turn, but 64 queries share a wave and thousands of waves are in flight: throughput, where k_knn_todo buys the
+// latency of a single query with a whole wave.
+template <int KMAX>
+__global__ void __launch_bounds__(kBlock)
+k_knn_todo_threads(const uint32_t* todo, const unsigned* n_todo, const float4* fit_pt, const int* fit_frame,
+                   const float4* idx_pt, const uint32_t* idx_first, const FrameInfo* fi, float inv_xy, float inv_z,
+                   float cell_xy, int coarse, int K, int* knn_out)
+{
+  const unsigned t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= *n_todo) return;
+  const uint32_t entry = todo[t];
+  const int me = (int)(entry & ~kTodoFromRing0);
+  const FrameInfo& F = fi[fit_frame[me]];
+  const float4 q = fit_pt[me];
+  const int dx = (F.div_b[0] + coarse - 1) / coarse, dy = (F.div_b[1] + coarse - 1) / coarse;
+  const int cqx = clampi(cell_unclamped(q.x, inv_xy, F.min_b[0]), 0, F.div_b[0] - 1) / coarse;
+  const int cqy = clampi(cell_unclamped(q.y, inv_xy, F.min_b[1]), 0, F.div_b[1] - 1) / coarse;
+  const int k = min(K, F.n_fit);
+  const float leaf_z = 1.0f / inv_z;
+  const float slack = F.slack / (float)coarse + (coarse > 1 ? 1e-6f : 0.f);
+  const float cell = cell_xy * (float)coarse;
+  const CoarseCols cols{idx_pt, idx_first, nullptr, (unsigned)(coarse > 1 ? F.ccol_off : F.col_off), dx};
+  knn_key lst[KMAX];
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) {
+    lst[j] = kKnnEmpty;
+    if (j < k) {
+      const int r = knn_out[(size_t)me * K + j];
+      if (r >= 0) {
+        const float4 p = fit_pt[r];
+        lst[j] = ((knn_key)__float_as_uint(dist2(q.x, q.y, q.z, p.x, p.y, p.z)) << 32) | (unsigned)r;
+      }
+    }
+  }
+  const int max_ring = max(max(cqx, dx - 1 - cqx), max(cqy, dy - 1 - cqy));
+  const int first_ring = (coarse > 1 || (entry & kTodoFromRing0)) ? 0 : kHaloKnn + 1;
+  knn_rings<CoarseCols, KMAX, true>(cols, q, cqx, cqy, dx, dy, first_ring, max_ring, k, slack, cell, leaf_z, lst);
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j)
+    if (j < K) knn_out[(size_t)me * K + j] = (j < k) ? (int)(unsigned)lst[j] : -1;
 }
 
 }  // namespace hope

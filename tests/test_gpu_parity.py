@@ -500,21 +500,25 @@ def test_knn_leftovers_through_the_coarse_index(hip_lib, oracle_lib, monkeypatch
     depth, t, q = synth_frames(2, first=70)
     xyz = synth.make_multilevel_cloud(300000, first_index=777, device="cpu").numpy()
     monkeypatch.setenv("HOPE_DEBUG_KNN_FINE_LIMIT", "0")
-    g_coarse = HopeContext(hip_lib)
+    g_coarse = HopeContext(hip_lib)                  # a thread per left-over query (k_knn_todo_threads)
+    monkeypatch.setenv("HOPE_DEBUG_TODO_THREADS", "0")
+    g_waves = HopeContext(hip_lib)                   # a wave per query (k_knn_todo over the coarse index)
+    monkeypatch.delenv("HOPE_DEBUG_TODO_THREADS")
     monkeypatch.setenv("HOPE_DEBUG_KNN_FINE_LIMIT", "1000000000")
     g_fine = HopeContext(hip_lib)
     monkeypatch.delenv("HOPE_DEBUG_KNN_FINE_LIMIT")
     o = HopeContext(oracle_lib)
-    for c in (g_coarse, g_fine, o):
+    gs = (g_coarse, g_waves, g_fine)
+    for c in gs + (o,):
         c.set_frame_poses(t, q)
         assert c.segment_depth(depth) == 0
     for f in range(2):
-        assert_frame_equal(o, g_coarse, f)
-        assert_frame_equal(o, g_fine, f)
-    for c in (g_coarse, g_fine, o):
+        for g in gs:
+            assert_frame_equal(o, g, f)
+    for c in gs + (o,):
         assert c.segment_cloud(xyz) == 0
-    assert_frame_equal(o, g_coarse, 0)
-    assert_frame_equal(o, g_fine, 0)
+    for g in gs:
+        assert_frame_equal(o, g, 0)
 
 
 def test_row_accessors_into_device_memory(hip_lib, oracle_lib):
