@@ -21,7 +21,7 @@ STAGE_OF = [  # kernel name fragment -> bench.py stage
     ("k_group_keys", "k_voxel_keys"), ("k_fit_sorted", "fit_column_index"), ("k_fit_col_table", "fit_column_index"),
     ("k_voxel_rank", "k_voxel_rank"), ("k_frame_vox_scan", "k_voxel_rank"), ("k_voxel_keys", "k_voxel_keys"), ("k_centroids", "k_centroids"), ("k_column_keys", "k_column_keys"),
     ("k_column_table", "k_column_table+gather"), ("k_gather_sorted", "k_column_table+gather"),
-    ("k_normals_tile", "k_normals"), ("k_fit_", "fit_gate+compact"), ("k_frame_fit", "fit_gate+compact"),
+    ("k_normals", "k_normals"), ("k_fit_", "fit_gate+compact"), ("k_frame_fit", "fit_gate+compact"),
     ("k_knn_todo", "k_knn_todo"), ("k_knn", "k_knn"), ("k_coarse", "k_knn_todo"), ("k_gather_coarse", "k_knn_todo"),
     ("k_seed_ranks", "labels(union+sweeps)"), ("k_union", "labels(union+sweeps)"),
     ("k_flatten_roots", "labels(union+sweeps)"), ("k_cross_edges", "labels(union+sweeps)"),
