@@ -778,11 +778,12 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
     const int* vf = F == 1 ? nullptr : d_vox_frame;
     if (c->normals_cap_small)
       hipLaunchKernelGGL((k_normals_direct<2>), dim3(nblk(n_vox)), dim3(kBlock), 0, s, spt, col_first, c->d_fi, c->inv_xy,
-                         c->inv_z, c->radius, c->r2, c->ring, c->own_lo, c->own_hi, (unsigned)n_vox, vf, d_normals);
+                         c->inv_z, c->radius, c->r2, c->ring, c->own_lo, c->own_hi, (unsigned)n_vox, vf, d_normals,
+                         c->ablate % 10);
     else
       hipLaunchKernelGGL((k_normals_direct<kNbCap>), dim3(nblk(n_vox)), dim3(kBlock), 0, s, spt, col_first, c->d_fi,
                          c->inv_xy, c->inv_z, c->radius, c->r2, c->ring, c->own_lo, c->own_hi, (unsigned)n_vox, vf,
-                         d_normals);
+                         d_normals, c->ablate % 10);
   } else {
 #define HOPE_NORMALS(CAP, SIDE)                                                                                       \
   hipLaunchKernelGGL((k_normals_tile<CAP, SIDE>), tile_grid, dim3(kBlock), 0, s, spt, col_first, c->d_fi, c->inv_xy, \

@@ -744,14 +744,13 @@ __device__ __forceinline__ float4 estimate_normal(const Cols& cols, const float4
   const int y0 = max(cqy - ring, 0), y1 = min(cqy + ring, dy - 1);
   const float zlo = q.z - radius - 1.5f * leaf_z, zhi = q.z + radius + 1.5f * leaf_z;
   int total = 0;
-  for (int cy = y0; cy <= y1; ++cy) {
-    for_window(cols, x0, x1, cy, zlo, zhi, [&](unsigned e, const float4& p) {
-      if (dist2(q.x, q.y, q.z, p.x, p.y, p.z) < r2) {
-        if (Cols::kNotes && total < CAPL) cand_e[total * kBlock] = (typename Cols::cand_t)e;
-        ++total;
-      }
-    });
-  }
+  auto note = [&](unsigned e, const float4& p) {
+    if (dist2(q.x, q.y, q.z, p.x, p.y, p.z) < r2) {
+      if (Cols::kNotes && total < CAPL) cand_e[total * kBlock] = (typename Cols::cand_t)e;
+      ++total;
+    }
+  };
+  for (int cy = y0; cy <= y1; ++cy) for_window(cols, x0, x1, cy, zlo, zhi, note);
   if (total < 3) return make_float4(NAN, NAN, NAN, NAN);
   if (ablate == 2) return make_float4((float)total, 0.f, 0.f, 0.f);
   float accu[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -847,7 +846,7 @@ template <int CAPL>
 __global__ void __launch_bounds__(kBlock, 4)
 k_normals_direct(const float4* spt, const uint32_t* col_first, const FrameInfo* fi, float inv_xy, float inv_z,
                  float radius, float r2, int ring, unsigned own_lo, unsigned own_hi, unsigned n, const int* vox_frame,
-                 float4* normals)
+                 float4* normals, int ablate)
 {
   __shared__ unsigned s_cand[CAPL * kBlock];
   const unsigned e = blockIdx.x * kBlock + threadIdx.x;
@@ -866,7 +865,7 @@ k_normals_direct(const float4* spt, const uint32_t* col_first, const FrameInfo* 
   gc.col_off = (unsigned)F.col_off;
   gc.dx = dx;
   normals[idx] = estimate_normal<GlobalColsNotes, CAPL>(gc, q, cqx, cqy, dx, dy, ring, radius, r2, 1.0f / inv_z,
-                                                        s_cand + threadIdx.x);
+                                                        s_cand + threadIdx.x, ablate);
 }
 
 // ---- A8: exact k nearest neighbours among the fit points ---------------------------------------
