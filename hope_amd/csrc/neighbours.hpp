@@ -1,14 +1,15 @@
-// neighbours.hpp — A6 (normals) and A8 (k nearest neighbours) on the column index, tiled
-// through LDS.
+// neighbours.hpp — A6 (normals) and A8 (k nearest neighbours) on the column index.
 //
 // The down-sampled cloud is sorted by (frame column, z cell); col_first[] gives the range of
-// every xy column.  A workgroup owns a 16x16-column tile of one frame: the points of the tile
-// plus a 2-column halo are contiguous per column row in the sorted array, so they are copied
-// into LDS with ~20 coalesced segment copies, together with a local column table.  Every
-// neighbour query of the tile's points is then served from LDS instead of dependent L2 gathers.
-// The same search code also runs on a "global" accessor (straight from HBM) for the cases the
-// tile cannot serve: a tile with more points than the LDS copy holds, and k-NN rings that leave
-// the halo.  Both accessors see the same points in the same arithmetic, so results are identical.
+// every xy column.  The search code (stencil scans in a z window, ordering network, sorted k-NN list, ring
+// expansion) is written once over an accessor of that index, and two sets of kernels run it:
+//   * k_normals_direct / k_knn_direct (the default): one thread per point in column order, the index read
+//     straight from HBM through the caches (GlobalColsT) -- the lanes of a wave are neighbours, so their scans
+//     share cache lines; k_knn_todo / k_knn_todo_threads finish the queries whose rings leave the fast range;
+//   * k_normals_tile / k_knn_tile (HOPE_DEBUG_NEIGHBOURS=tiles; the first implementation, kept as a cross-check):
+//     a workgroup owns a tile of columns, copies tile + halo into LDS with a local column table (TileCols) and
+//     serves every query of the tile from there.
+// Both accessors see the same points in the same arithmetic, so results are identical.
 //
 // Reference semantics: pcl::NormalEstimation with a radius search (utilities.cpp:428-446) and
 // ZGrowing::findPointNeighbours' nearestKSearch (z_growing.cpp:196-226); see kernels.hpp for the
