@@ -59,12 +59,40 @@ struct GlobalColsT {  // a column index straight from HBM: W_IS_RANK false = eve
   static constexpr bool kLds = false;
   static constexpr bool kNotes = false;  // A6 re-scans the stencil for every pick instead of noting the neighbours
   typedef unsigned short cand_t;
+  __device__ __forceinline__ unsigned note_base() const { return 0u; }  // (notes hold position - note_base())
 };
 typedef GlobalColsT<false> GlobalCols;
 typedef GlobalColsT<true> CoarseCols;
 struct GlobalColsNotes : GlobalCols {  // ... or notes them as 32-bit positions in the sorted array (k_normals_direct)
   static constexpr bool kNotes = true;
   typedef unsigned cand_t;
+};
+// The column table straight from HBM, the points from an LDS copy of ONE contiguous stretch [w0, w0 + n) of the
+// sorted array (k_normals_direct: the stretch that holds every stencil row of the workgroup's 256 consecutive points).
+struct WindowCols {
+  const float4* s_pt;
+  unsigned w0;
+  const uint32_t* col_first;
+  unsigned col_off;
+  int dx;
+  __device__ __forceinline__ void range(int cx, int cy, unsigned& lo, unsigned& hi) const
+  {
+    const unsigned c = col_off + (unsigned)(cy * dx + cx);
+    lo = col_first[c];
+    hi = col_first[c + 1];
+  }
+  __device__ __forceinline__ void row_range(int cx0, int cx1, int cy, unsigned& lo, unsigned& hi) const
+  {
+    const unsigned c = col_off + (unsigned)(cy * dx);
+    lo = col_first[c + cx0];
+    hi = col_first[c + cx1 + 1];
+  }
+  __device__ __forceinline__ float4 pt(unsigned e) const { return s_pt[e - w0]; }
+  __device__ __forceinline__ int fit(unsigned, const float4& p) const { return __float_as_int(p.w); }
+  static constexpr bool kLds = false;
+  static constexpr bool kNotes = true;
+  typedef unsigned short cand_t;
+  __device__ __forceinline__ unsigned note_base() const { return w0; }
 };
 
 template <int HALO>
@@ -90,6 +118,7 @@ struct TileCols {  // LDS copy of a tile and its halo
   static constexpr bool kLds = true;
   static constexpr bool kNotes = true;
   typedef unsigned short cand_t;
+  __device__ __forceinline__ unsigned note_base() const { return 0u; }
 };
 
 template <bool WITH_FIT, int HALO>
@@ -710,7 +739,7 @@ __device__ __forceinline__ void accumulate_sorted(const Cols& cols, const float4
   float cd[N];
   unsigned ce[N];
 #pragma unroll
-  for (int s = 0; s < N; ++s) ce[s] = s < total ? (unsigned)cand_e[s * kBlock] : 0u;
+  for (int s = 0; s < N; ++s) ce[s] = (s < total ? (unsigned)cand_e[s * kBlock] : 0u) + cols.note_base();
 #pragma unroll
   for (int s = 0; s < N; ++s) {
     const float4 p = cols.pt(ce[s]);
@@ -747,7 +776,7 @@ __device__ __forceinline__ float4 estimate_normal(const Cols& cols, const float4
   int total = 0;
   auto note = [&](unsigned e, const float4& p) {
     if (dist2(q.x, q.y, q.z, p.x, p.y, p.z) < r2) {
-      if (Cols::kNotes && total < CAPL) cand_e[total * kBlock] = (typename Cols::cand_t)e;
+      if (Cols::kNotes && total < CAPL) cand_e[total * kBlock] = (typename Cols::cand_t)(e - cols.note_base());
       ++total;
     }
   };
@@ -843,19 +872,35 @@ k_normals_tile(const float4* spt, const uint32_t* col_first, const FrameInfo* fi
 // a wave are neighbours in a column or in adjacent columns, so their scans read the same cache lines.
 // (4 waves per SIMD at 128 VGPRs and 44 bytes of spills beat 3 at 135 and none: 1.29 against 1.52 ms on the frame
 // batch; 5 at 96 VGPRs lose again)
+//
+// The sorted array is row-major in (y, x), so everything the 256 consecutive points of a workgroup can find lies in
+// ONE stretch of it: from the first stencil row of the first point to the last stencil row of the last one -- the
+// workgroup's own points and 2 * ring grid rows.  When that stretch fits kWinCap points (depth frames: rows of
+// ~100 points) it is copied to LDS once and every scan and re-fetch reads it there (WindowCols): the kernel is
+// bound by the 64 B/clk of the L1 otherwise, at 16 lines per wave-level float4 load.  Tall columns (walls,
+// clutter) do not fit: straight from HBM then, block by block.
+constexpr int kWinCap = 1024;  // 16 KiB of points + 16 KiB of 16-bit notes = the 32 KiB of 32-bit notes of the other path
+
 template <int CAPL>
 __global__ void __launch_bounds__(kBlock, 4)
 k_normals_direct(const float4* spt, const uint32_t* col_first, const FrameInfo* fi, float inv_xy, float inv_z,
                  float radius, float r2, int ring, unsigned own_lo, unsigned own_hi, unsigned n, const int* vox_frame,
                  float4* normals, int ablate)
 {
-  __shared__ unsigned s_cand[CAPL * kBlock];
+  constexpr int kNoteBytes = CAPL * kBlock * 4;
+  constexpr int kWinBytes = kWinCap * 16 + CAPL * kBlock * 2;
+  __shared__ __attribute__((aligned(16))) unsigned char s_raw[kNoteBytes > kWinBytes ? kNoteBytes : kWinBytes];
+  __shared__ unsigned s_w[2];
   const unsigned e = blockIdx.x * kBlock + threadIdx.x;
-  if (e >= n) return;
-  const float4 q = spt[e];
-  const unsigned idx = __float_as_uint(q.w);
-  if (idx < own_lo || idx >= own_hi) return;  // (staged multi-GPU call: another rank's point)
-  const FrameInfo& F = fi[vox_frame ? vox_frame[idx] : 0];
+  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+  unsigned idx = 0u;
+  bool valid = e < n;
+  if (valid) {
+    q = spt[e];
+    idx = __float_as_uint(q.w);
+    valid = idx >= own_lo && idx < own_hi;  // (staged multi-GPU call: another rank's point)
+  }
+  const FrameInfo& F = fi[(valid && vox_frame) ? vox_frame[idx] : 0];
   const int dx = F.div_b[0], dy = F.div_b[1];
   const int cqx = clampi(cell_unclamped(q.x, inv_xy, F.min_b[0]), 0, dx - 1);
   const int cqy = clampi(cell_unclamped(q.y, inv_xy, F.min_b[1]), 0, dy - 1);
@@ -865,8 +910,44 @@ k_normals_direct(const float4* spt, const uint32_t* col_first, const FrameInfo* 
   gc.fit_rank = nullptr;
   gc.col_off = (unsigned)F.col_off;
   gc.dx = dx;
-  normals[idx] = estimate_normal<GlobalColsNotes, CAPL>(gc, q, cqx, cqy, dx, dy, ring, radius, r2, 1.0f / inv_z,
-                                                        s_cand + threadIdx.x, ablate);
+  // the stretch of the sorted array that holds every stencil row of this workgroup
+  if (threadIdx.x == 0) {
+    s_w[0] = 0xffffffffu;
+    s_w[1] = 0u;
+  }
+  __syncthreads();
+  unsigned lo = 0xffffffffu, hi = 0u;
+  if (valid) {
+    const int x0 = max(cqx - ring, 0), x1 = min(cqx + ring, dx - 1);
+    unsigned t;
+    gc.row_range(x0, x1, max(cqy - ring, 0), lo, t);
+    gc.row_range(x0, x1, min(cqy + ring, dy - 1), t, hi);
+  }
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    lo = min(lo, (unsigned)__shfl_xor((int)lo, off));
+    hi = max(hi, (unsigned)__shfl_xor((int)hi, off));
+  }
+  if ((threadIdx.x & (kWave - 1)) == 0 && hi > 0u) {
+    atomicMin(&s_w[0], lo);
+    atomicMax(&s_w[1], hi);
+  }
+  __syncthreads();
+  const unsigned w0 = s_w[0], w1 = s_w[1];
+  if (w1 > w0 && w1 - w0 <= (unsigned)kWinCap) {  // (block-uniform)
+    float4* s_pt = reinterpret_cast<float4*>(s_raw);
+    unsigned short* s_note = reinterpret_cast<unsigned short*>(s_raw + kWinCap * 16);
+    for (unsigned i = threadIdx.x; i < w1 - w0; i += kBlock) s_pt[i] = spt[w0 + i];
+    __syncthreads();
+    if (!valid) return;
+    const WindowCols wc{s_pt, w0, col_first, (unsigned)F.col_off, dx};
+    normals[idx] = estimate_normal<WindowCols, CAPL>(wc, q, cqx, cqy, dx, dy, ring, radius, r2, 1.0f / inv_z,
+                                                     s_note + threadIdx.x, ablate);
+  } else {
+    if (!valid) return;
+    normals[idx] = estimate_normal<GlobalColsNotes, CAPL>(gc, q, cqx, cqy, dx, dy, ring, radius, r2, 1.0f / inv_z,
+                                                          reinterpret_cast<unsigned*>(s_raw) + threadIdx.x, ablate);
+  }
 }
 
 // ---- A8: exact k nearest neighbours among the fit points ---------------------------------------
@@ -1057,9 +1138,9 @@ k_knn_tile(const float4* spt, const uint32_t* col_first, const int* fit_rank, co
 // k_knn_tile; the lanes of a wave are neighbours on a surface, so their scans share cache lines.
 // the fast pass and the ring expansion of one query; FULL: k == KMAX, known at compile time (the list code then has
 // no selects on k)
-template <int KMAX, bool FULL>
-__device__ __forceinline__ bool knn_direct_query(const CoarseCols& tc, const float4 q, int cqx, int cqy, int dx, int dy,
-                                                 int k_any, float slack, float cell_xy, float leaf_z,
+template <int KMAX, bool FULL, class Fast>
+__device__ __forceinline__ bool knn_direct_query(const Fast& fc, const CoarseCols& tc, const float4 q, int cqx, int cqy,
+                                                 int dx, int dy, int k_any, float slack, float cell_xy, float leaf_z,
                                                  knn_key (&lst)[KMAX])
 {
   const int k = FULL ? KMAX : k_any;
@@ -1070,23 +1151,23 @@ __device__ __forceinline__ bool knn_direct_query(const CoarseCols& tc, const flo
   if (reach2 > 0.f) {
     const int x0 = max(cqx - 2, 0), x1 = min(cqx + 2, dx - 1);
     const float zlo = q.z - zwin, zhi = q.z + zwin;
-    auto offer = [&](unsigned e, const float4& p) { knn_offer<CoarseCols, KMAX>(tc, q, e, p, k, lst); };
+    auto offer = [&](unsigned e, const float4& p) { knn_offer<Fast, KMAX>(fc, q, e, p, k, lst); };
     const int xc0 = max(cqx - 1, 0), xc1 = min(cqx + 1, dx - 1);
 #pragma unroll 1
     for (int s = 0; s < 3; ++s) {
       const int cy = cqy + (s == 0 ? 0 : (s == 1 ? -1 : 1));
       if (cy < 0 || cy >= dy) continue;
-      for_window(tc, xc0, xc1, cy, zlo, zhi, offer);
+      for_window(fc, xc0, xc1, cy, zlo, zhi, offer);
     }
 #pragma unroll 1
     for (int s = 0; s < 5; ++s) {
       const int cy = cqy + s - 2;
       if (cy < 0 || cy >= dy) continue;
       if (s == 0 || s == 4) {
-        for_window(tc, x0, x1, cy, zlo, zhi, offer);
+        for_window(fc, x0, x1, cy, zlo, zhi, offer);
       } else {
-        if (cqx - 2 >= 0) for_window(tc, cqx - 2, cqx - 2, cy, zlo, zhi, offer);
-        if (cqx + 2 < dx) for_window(tc, cqx + 2, cqx + 2, cy, zlo, zhi, offer);
+        if (cqx - 2 >= 0) for_window(fc, cqx - 2, cqx - 2, cy, zlo, zhi, offer);
+        if (cqx + 2 < dx) for_window(fc, cqx + 2, cqx + 2, cy, zlo, zhi, offer);
       }
     }
     done = knn_kth<KMAX>(k, lst) < reach2 * reach2 * 0.999999f;
@@ -1100,35 +1181,81 @@ __device__ __forceinline__ bool knn_direct_query(const CoarseCols& tc, const flo
 }
 
 // (K <= 8: 5 waves per SIMD at 96 VGPRs; 6 at 80 spill too much: 2.4 against 1.33 ms)
+// The fast pass reads the 5x5 columns from an LDS copy of the workgroup's stretch of the sorted fit points when
+// that fits (see k_normals_direct); the ring expansion of the few queries it does not settle reads HBM.
 template <int KMAX>
 __global__ void __launch_bounds__(kBlock, KMAX <= 8 ? 5 : 1)
 k_knn_direct(const float4* spt_fit, const uint32_t* col_first_fit, const FrameInfo* fi, const int* fit_frame,
              float inv_xy, float inv_z, float cell_xy, int K, const uint32_t* fit_idx, unsigned own_lo, unsigned own_hi,
              unsigned n_fit, int* knn_out, uint32_t* todo, unsigned* n_todo)
 {
+  __shared__ float4 s_pt[kWinCap];
+  __shared__ unsigned s_w[2];
   const unsigned e0 = blockIdx.x * kBlock + threadIdx.x;
-  if (e0 >= n_fit) return;
-  const float4 q = spt_fit[e0];
-  const int me = __float_as_int(q.w);
-  if (own_hi - own_lo != 0xffffffffu) {  // staged multi-GPU call: only this rank's share of the queries
-    const unsigned idx = fit_idx[me];
-    if (idx < own_lo || idx >= own_hi) return;
+  bool valid = e0 < n_fit;
+  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+  int me = 0;
+  if (valid) {
+    q = spt_fit[e0];
+    me = __float_as_int(q.w);
+    if (own_hi - own_lo != 0xffffffffu) {  // staged multi-GPU call: only this rank's share of the queries
+      const unsigned idx = fit_idx[me];
+      valid = idx >= own_lo && idx < own_hi;
+    }
   }
-  const FrameInfo& F = fi[fit_frame ? fit_frame[me] : 0];
+  const FrameInfo& F = fi[(valid && fit_frame) ? fit_frame[me] : 0];
   const int dx = F.div_b[0], dy = F.div_b[1];
   const int cqx = clampi(cell_unclamped(q.x, inv_xy, F.min_b[0]), 0, dx - 1);
   const int cqy = clampi(cell_unclamped(q.y, inv_xy, F.min_b[1]), 0, dy - 1);
   const float leaf_z = 1.0f / inv_z;
   const int k = min(K, F.n_fit);
   const CoarseCols tc{spt_fit, col_first_fit, nullptr, (unsigned)F.col_off, dx};
+  if (threadIdx.x == 0) {
+    s_w[0] = 0xffffffffu;
+    s_w[1] = 0u;
+  }
+  __syncthreads();
+  unsigned lo = 0xffffffffu, hi = 0u;
+  if (valid) {
+    const int x0 = max(cqx - 2, 0), x1 = min(cqx + 2, dx - 1);
+    unsigned t;
+    tc.row_range(x0, x1, max(cqy - 2, 0), lo, t);
+    tc.row_range(x0, x1, min(cqy + 2, dy - 1), t, hi);
+  }
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    lo = min(lo, (unsigned)__shfl_xor((int)lo, off));
+    hi = max(hi, (unsigned)__shfl_xor((int)hi, off));
+  }
+  if ((threadIdx.x & (kWave - 1)) == 0 && hi > 0u) {
+    atomicMin(&s_w[0], lo);
+    atomicMax(&s_w[1], hi);
+  }
+  __syncthreads();
+  const unsigned w0 = s_w[0], w1 = s_w[1];
+  const bool window = w1 > w0 && w1 - w0 <= (unsigned)kWinCap;  // (block-uniform)
+  if (window) {
+    for (unsigned i = threadIdx.x; i < w1 - w0; i += kBlock) s_pt[i] = spt_fit[w0 + i];
+    __syncthreads();
+  }
+  if (!valid) return;
   knn_key lst[KMAX];
 #pragma unroll
   for (int j = 0; j < KMAX; ++j) lst[j] = kKnnEmpty;
+  const bool full = __all(k == KMAX);  // wave-uniform: the usual case (K = 8 and frames of more than 8 fit points)
   bool done;
-  if (__all(k == KMAX))  // wave-uniform: the usual case (K = 8 and frames of more than 8 fit points)
-    done = knn_direct_query<KMAX, true>(tc, q, cqx, cqy, dx, dy, k, F.slack, cell_xy, leaf_z, lst);
-  else
-    done = knn_direct_query<KMAX, false>(tc, q, cqx, cqy, dx, dy, k, F.slack, cell_xy, leaf_z, lst);
+  if (window) {
+    const WindowCols wc{s_pt, w0, col_first_fit, (unsigned)F.col_off, dx};
+    if (full)
+      done = knn_direct_query<KMAX, true>(wc, tc, q, cqx, cqy, dx, dy, k, F.slack, cell_xy, leaf_z, lst);
+    else
+      done = knn_direct_query<KMAX, false>(wc, tc, q, cqx, cqy, dx, dy, k, F.slack, cell_xy, leaf_z, lst);
+  } else {
+    if (full)
+      done = knn_direct_query<KMAX, true>(tc, tc, q, cqx, cqy, dx, dy, k, F.slack, cell_xy, leaf_z, lst);
+    else
+      done = knn_direct_query<KMAX, false>(tc, tc, q, cqx, cqy, dx, dy, k, F.slack, cell_xy, leaf_z, lst);
+  }
 #pragma unroll
   for (int j = 0; j < KMAX; ++j)
     if (j < K) knn_out[(size_t)me * K + j] = (j < k) ? (int)(unsigned)lst[j] : -1;
