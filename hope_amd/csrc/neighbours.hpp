@@ -767,11 +767,26 @@ __device__ __forceinline__ void accumulate_sorted(const Cols& cols, const float4
 template <class Cols, int CAPL>
 __device__ __forceinline__ float4 estimate_normal(const Cols& cols, const float4 q, int cqx, int cqy, int dx, int dy,
                                                   int ring, float radius, float r2, float leaf_z,
-                                                  typename Cols::cand_t* cand_e, int ablate = 0)
+                                                  typename Cols::cand_t* cand_e, int ablate, float inv_xy, float slack)
 {
   static_assert(CAPL <= kNbCap, "the largest sorting network has kNbCap inputs");
-  const int x0 = max(cqx - ring, 0), x1 = min(cqx + ring, dx - 1);
-  const int y0 = max(cqy - ring, 0), y1 = min(cqy + ring, dy - 1);
+  // The stencil: `ring` columns to every side reach the radius from ANY place in the query's cell; from where the
+  // query actually is, the outermost ones mostly cannot (radius 1.01 cells: the second column to the left only
+  // within 0.01 cells of the left edge).  A point k columns to the left is at least (u + k - 1 - slack) cells away
+  // in x, u the query's place in its cell, slack the float-rounding slack of a column index (FrameInfo::slack);
+  // k columns to the right: (k - u - slack).  The factors leave 1e-5 to the roundings of the distance itself.
+  int kl = ring, kr = ring, kd = ring, ku = ring;
+  {
+    const float cell = 1.0f / inv_xy, lim = radius * 1.00001f;
+    const float sx = q.x * inv_xy, sy = q.y * inv_xy;
+    const float u = sx - floorf(sx), v = sy - floorf(sy);
+    while (kl > 1 && (u + (float)(kl - 1) - slack) * cell * 0.999999f > lim) --kl;
+    while (kr > 1 && ((float)kr - u - slack) * cell * 0.999999f > lim) --kr;
+    while (kd > 1 && (v + (float)(kd - 1) - slack) * cell * 0.999999f > lim) --kd;
+    while (ku > 1 && ((float)ku - v - slack) * cell * 0.999999f > lim) --ku;
+  }
+  const int x0 = max(cqx - kl, 0), x1 = min(cqx + kr, dx - 1);
+  const int y0 = max(cqy - kd, 0), y1 = min(cqy + ku, dy - 1);
   const float zlo = q.z - radius - 1.5f * leaf_z, zhi = q.z + radius + 1.5f * leaf_z;
   int total = 0;
   auto note = [&](unsigned e, const float4& p) {
@@ -856,13 +871,14 @@ k_normals_tile(const float4* spt, const uint32_t* col_first, const FrameInfo* fi
           const unsigned idx = __float_as_uint(q.w);
           if (idx < own_lo || idx >= own_hi) return;  // (staged multi-GPU call: another rank's point)
           normals[idx] = estimate_normal<TileCols<kHaloNormals>, CAPL>(tc, q, cqx, cqy, dx, dy, ring, radius, r2, leaf_z,
-                                                                       cand_e, ablate);
+                                                                       cand_e, ablate, inv_xy, F.slack);
         },
         [&](const float4& q, int cqx, int cqy) {
           const unsigned idx = __float_as_uint(q.w);
           if (idx < own_lo || idx >= own_hi) return;
           normals[idx] =
-              estimate_normal<GlobalCols, CAPL>(gc, q, cqx, cqy, dx, dy, ring, radius, r2, leaf_z, cand_e, ablate);
+              estimate_normal<GlobalCols, CAPL>(gc, q, cqx, cqy, dx, dy, ring, radius, r2, leaf_z, cand_e, ablate, inv_xy,
+                                                F.slack);
         });
   }
 }
@@ -942,11 +958,11 @@ k_normals_direct(const float4* spt, const uint32_t* col_first, const FrameInfo* 
     if (!valid) return;
     const WindowCols wc{s_pt, w0, col_first, (unsigned)F.col_off, dx};
     normals[idx] = estimate_normal<WindowCols, CAPL>(wc, q, cqx, cqy, dx, dy, ring, radius, r2, 1.0f / inv_z,
-                                                     s_note + threadIdx.x, ablate);
+                                                     s_note + threadIdx.x, ablate, inv_xy, F.slack);
   } else {
     if (!valid) return;
     normals[idx] = estimate_normal<GlobalColsNotes, CAPL>(gc, q, cqx, cqy, dx, dy, ring, radius, r2, 1.0f / inv_z,
-                                                          reinterpret_cast<unsigned*>(s_raw) + threadIdx.x, ablate);
+                                                          reinterpret_cast<unsigned*>(s_raw) + threadIdx.x, ablate, inv_xy, F.slack);
   }
 }
 
@@ -1189,6 +1205,7 @@ k_knn_direct(const float4* spt_fit, const uint32_t* col_first_fit, const FrameIn
              float inv_xy, float inv_z, float cell_xy, int K, const uint32_t* fit_idx, unsigned own_lo, unsigned own_hi,
              unsigned n_fit, int* knn_out, uint32_t* todo, unsigned* n_todo)
 {
+  constexpr int kWinCap = 1536;  // (k-NN: no notes, so LDS has room for more than the normals kernel's 1024)
   __shared__ float4 s_pt[kWinCap];
   __shared__ unsigned s_w[2];
   const unsigned e0 = blockIdx.x * kBlock + threadIdx.x;
