@@ -764,6 +764,20 @@ __device__ __forceinline__ void accumulate_sorted(const Cols& cols, const float4
 }
 #undef HOPE_CE
 
+// columns / rows of the stencil that can hold a point within `radius` of q (see estimate_normal)
+__device__ __forceinline__ void stencil_reach(const float4 q, int ring, float radius, float inv_xy, float slack, int& kl,
+                                              int& kr, int& kd, int& ku)
+{
+  kl = kr = kd = ku = ring;
+  const float cell = 1.0f / inv_xy, lim = radius * 1.00001f;
+  const float sx = q.x * inv_xy, sy = q.y * inv_xy;
+  const float u = sx - floorf(sx), v = sy - floorf(sy);
+  while (kl > 1 && (u + (float)(kl - 1) - slack) * cell * 0.999999f > lim) --kl;
+  while (kr > 1 && ((float)kr - u - slack) * cell * 0.999999f > lim) --kr;
+  while (kd > 1 && (v + (float)(kd - 1) - slack) * cell * 0.999999f > lim) --kd;
+  while (ku > 1 && ((float)ku - v - slack) * cell * 0.999999f > lim) --ku;
+}
+
 template <class Cols, int CAPL>
 __device__ __forceinline__ float4 estimate_normal(const Cols& cols, const float4 q, int cqx, int cqy, int dx, int dy,
                                                   int ring, float radius, float r2, float leaf_z,
@@ -775,16 +789,8 @@ __device__ __forceinline__ float4 estimate_normal(const Cols& cols, const float4
   // within 0.01 cells of the left edge).  A point k columns to the left is at least (u + k - 1 - slack) cells away
   // in x, u the query's place in its cell, slack the float-rounding slack of a column index (FrameInfo::slack);
   // k columns to the right: (k - u - slack).  The factors leave 1e-5 to the roundings of the distance itself.
-  int kl = ring, kr = ring, kd = ring, ku = ring;
-  {
-    const float cell = 1.0f / inv_xy, lim = radius * 1.00001f;
-    const float sx = q.x * inv_xy, sy = q.y * inv_xy;
-    const float u = sx - floorf(sx), v = sy - floorf(sy);
-    while (kl > 1 && (u + (float)(kl - 1) - slack) * cell * 0.999999f > lim) --kl;
-    while (kr > 1 && ((float)kr - u - slack) * cell * 0.999999f > lim) --kr;
-    while (kd > 1 && (v + (float)(kd - 1) - slack) * cell * 0.999999f > lim) --kd;
-    while (ku > 1 && ((float)ku - v - slack) * cell * 0.999999f > lim) --ku;
-  }
+  int kl, kr, kd, ku;
+  stencil_reach(q, ring, radius, inv_xy, slack, kl, kr, kd, ku);
   const int x0 = max(cqx - kl, 0), x1 = min(cqx + kr, dx - 1);
   const int y0 = max(cqy - kd, 0), y1 = min(cqy + ku, dy - 1);
   const float zlo = q.z - radius - 1.5f * leaf_z, zhi = q.z + radius + 1.5f * leaf_z;
@@ -934,10 +940,12 @@ k_normals_direct(const float4* spt, const uint32_t* col_first, const FrameInfo* 
   __syncthreads();
   unsigned lo = 0xffffffffu, hi = 0u;
   if (valid) {
-    const int x0 = max(cqx - ring, 0), x1 = min(cqx + ring, dx - 1);
+    int kl, kr, kd, ku;
+    stencil_reach(q, ring, radius, inv_xy, F.slack, kl, kr, kd, ku);
+    const int x0 = max(cqx - kl, 0), x1 = min(cqx + kr, dx - 1);
     unsigned t;
-    gc.row_range(x0, x1, max(cqy - ring, 0), lo, t);
-    gc.row_range(x0, x1, min(cqy + ring, dy - 1), t, hi);
+    gc.row_range(x0, x1, max(cqy - kd, 0), lo, t);
+    gc.row_range(x0, x1, min(cqy + ku, dy - 1), t, hi);
   }
 #pragma unroll
   for (int off = kWave / 2; off > 0; off >>= 1) {
