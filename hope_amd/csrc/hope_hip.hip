@@ -771,19 +771,27 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   };
   const int side_n = c->tile_side ? c->tile_side : tile_side(n_vox);
   const dim3 tile_grid = tile_grid_of(side_n);
+  // the flags of the A7 gate, in index order and in the order of the column index: written by k_normals_direct
+  // itself when it computes every normal (gate_fused), else by k_fit_flags / k_fit_sorted_flags below
+  uint32_t *flags, *sflags;
+  ALLOC(flags, uint32_t, (size_t)n_vox + 1);
+  ALLOC(sflags, uint32_t, (size_t)n_vox + 1);
+  bool gate_fused = false;
   if (c->inj_normals) {
     HIPCHK(hipMemcpyAsync(d_normals, c->inj_normals, sizeof(float4) * (size_t)n_vox,
                           c->inj_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
   } else if (c->normals_direct) {
     const int* vf = F == 1 ? nullptr : d_vox_frame;
+    gate_fused = c->own_lo == 0u && c->own_hi == 0xffffffffu && c->ablate == 0;
+    uint32_t* ff = gate_fused ? flags : nullptr;
     if (c->normals_cap_small)
       hipLaunchKernelGGL((k_normals_direct<2>), dim3(nblk(n_vox)), dim3(kBlock), 0, s, spt, col_first, c->d_fi, c->inv_xy,
                          c->inv_z, c->radius, c->r2, c->ring, c->own_lo, c->own_hi, (unsigned)n_vox, vf, d_normals,
-                         c->ablate % 10);
+                         c->ablate % 10, c->th_norm, ff, sflags);
     else
       hipLaunchKernelGGL((k_normals_direct<kNbCap>), dim3(nblk(n_vox)), dim3(kBlock), 0, s, spt, col_first, c->d_fi,
                          c->inv_xy, c->inv_z, c->radius, c->r2, c->ring, c->own_lo, c->own_hi, (unsigned)n_vox, vf,
-                         d_normals, c->ablate % 10);
+                         d_normals, c->ablate % 10, c->th_norm, ff, sflags);
   } else {
 #define HOPE_NORMALS(CAP, SIDE)                                                                                       \
   hipLaunchKernelGGL((k_normals_tile<CAP, SIDE>), tile_grid, dim3(kBlock), 0, s, spt, col_first, c->d_fi, c->inv_xy, \
@@ -798,12 +806,12 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   prof_close(c, ST_NORMALS, pm, (16.0 + 16.0) * n_vox);
   if (c->stop_stage == 1) return HOPE_OK;
   // ---- A7 gate + compaction ---------------------------------------------------------
-  uint32_t *flags, *fscan;
-  ALLOC(flags, uint32_t, (size_t)n_vox + 1);
+  uint32_t* fscan;
   ALLOC(fscan, uint32_t, (size_t)n_vox + 1);
   pm = prof_mark(c);
-  hipLaunchKernelGGL(k_fit_flags, dim3(nblk((size_t)n_vox + 1)), dim3(kBlock), 0, s, d_normals, n_vox, c->th_norm,
-                     flags);
+  if (!gate_fused)
+    hipLaunchKernelGGL(k_fit_flags, dim3(nblk((size_t)n_vox + 1)), dim3(kBlock), 0, s, d_normals, n_vox, c->th_norm,
+                       flags);
   HIPCHK(exclusive_scan_u32(pa, flags, fscan, (size_t)n_vox + 1, s));
   hipLaunchKernelGGL(k_frame_fit_ranges, dim3(nblk(F)), dim3(kBlock), 0, s, c->d_fi, F, fscan, c->d_glob);
   HIPCHK(hipMemcpyAsync(&c->d_glob->pad, fscan + n_vox, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
@@ -843,14 +851,15 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   ALLOC(todo, uint32_t, n_fit);
   // the column index of the fit points alone: the k-NN tiles then hold and scan only points that can
   // be neighbours
-  uint32_t *sflags, *fpos, *col_first_fit;
+  uint32_t *fpos, *col_first_fit;
   float4* spt_fit;
-  ALLOC(sflags, uint32_t, (size_t)n_vox + 1);
   ALLOC(fpos, uint32_t, (size_t)n_vox + 1);
   ALLOC(col_first_fit, uint32_t, (size_t)total_cols + 1);
   ALLOC(spt_fit, float4, n_fit);
   pm = prof_mark(c);
-  hipLaunchKernelGGL(k_fit_sorted_flags, dim3(nblk((size_t)n_vox + 1)), dim3(kBlock), 0, s, spt, fit_rank, n_vox, sflags);
+  if (!gate_fused)
+    hipLaunchKernelGGL(k_fit_sorted_flags, dim3(nblk((size_t)n_vox + 1)), dim3(kBlock), 0, s, spt, fit_rank, n_vox,
+                       sflags);
   HIPCHK(exclusive_scan_u32(pa, sflags, fpos, (size_t)n_vox + 1, s));
   hipLaunchKernelGGL(k_fit_sorted_scatter, dim3(nblk(n_vox)), dim3(kBlock), 0, s, spt, fit_rank, sflags, fpos, n_vox,
                      spt_fit);

@@ -907,8 +907,15 @@ template <int CAPL>
 __global__ void __launch_bounds__(kBlock, 4)
 k_normals_direct(const float4* spt, const uint32_t* col_first, const FrameInfo* fi, float inv_xy, float inv_z,
                  float radius, float r2, int ring, unsigned own_lo, unsigned own_hi, unsigned n, const int* vox_frame,
-                 float4* normals, int ablate)
+                 float4* normals, int ablate, float th_norm, uint32_t* fit_flag, uint32_t* fit_flag_sorted)
 {
+  // fit_flag != NULL (a call that computes every normal): the A7 gate |nz| > th_norm is written here too, in index
+  // order and in sorted order, n + 1 entries each -- the inputs of the two compactions, which then need no pass of
+  // their own over the normals
+  if (fit_flag && blockIdx.x == 0 && threadIdx.x == 0) {
+    fit_flag[n] = 0u;
+    fit_flag_sorted[n] = 0u;
+  }
   constexpr int kNoteBytes = CAPL * kBlock * 4;
   constexpr int kWinBytes = kWinCap * 16 + CAPL * kBlock * 2;
   __shared__ __attribute__((aligned(16))) unsigned char s_raw[kNoteBytes > kWinBytes ? kNoteBytes : kWinBytes];
@@ -958,6 +965,7 @@ k_normals_direct(const float4* spt, const uint32_t* col_first, const FrameInfo* 
   }
   __syncthreads();
   const unsigned w0 = s_w[0], w1 = s_w[1];
+  float4 nrm;
   if (w1 > w0 && w1 - w0 <= (unsigned)kWinCap) {  // (block-uniform)
     float4* s_pt = reinterpret_cast<float4*>(s_raw);
     unsigned short* s_note = reinterpret_cast<unsigned short*>(s_raw + kWinCap * 16);
@@ -965,12 +973,19 @@ k_normals_direct(const float4* spt, const uint32_t* col_first, const FrameInfo* 
     __syncthreads();
     if (!valid) return;
     const WindowCols wc{s_pt, w0, col_first, (unsigned)F.col_off, dx};
-    normals[idx] = estimate_normal<WindowCols, CAPL>(wc, q, cqx, cqy, dx, dy, ring, radius, r2, 1.0f / inv_z,
-                                                     s_note + threadIdx.x, ablate, inv_xy, F.slack);
+    nrm = estimate_normal<WindowCols, CAPL>(wc, q, cqx, cqy, dx, dy, ring, radius, r2, 1.0f / inv_z,
+                                            s_note + threadIdx.x, ablate, inv_xy, F.slack);
   } else {
     if (!valid) return;
-    normals[idx] = estimate_normal<GlobalColsNotes, CAPL>(gc, q, cqx, cqy, dx, dy, ring, radius, r2, 1.0f / inv_z,
-                                                          reinterpret_cast<unsigned*>(s_raw) + threadIdx.x, ablate, inv_xy, F.slack);
+    nrm = estimate_normal<GlobalColsNotes, CAPL>(gc, q, cqx, cqy, dx, dy, ring, radius, r2, 1.0f / inv_z,
+                                                 reinterpret_cast<unsigned*>(s_raw) + threadIdx.x, ablate, inv_xy,
+                                                 F.slack);
+  }
+  normals[idx] = nrm;
+  if (fit_flag) {
+    const uint32_t f = fabsf(nrm.z) > th_norm ? 1u : 0u;  // NaN fails (k_fit_flags)
+    fit_flag[idx] = f;
+    fit_flag_sorted[e] = f;
   }
 }
 
