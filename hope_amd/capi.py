@@ -175,6 +175,12 @@ class HopeLib:
             f = getattr(self.dll, prefix + "fast_division_active")
             f.restype, f.argtypes = C.c_int, [vp]
             self.fn["fast_division_active"] = f
+            f = getattr(self.dll, prefix + "debug_chain_sums")
+            f.restype, f.argtypes = C.c_int, [vp, vp, C.c_size_t, i32, vp, vp]
+            self.fn["debug_chain_sums"] = f
+            f = getattr(self.dll, prefix + "debug_xs_stats")
+            f.restype, f.argtypes = C.c_int, [vp, vp]
+            self.fn["debug_xs_stats"] = f
 
     def default_config(self):
         cfg = HopeConfig()
@@ -473,6 +479,22 @@ class HopeContext:
                 self._check(r, "get_upon_cluster")
             out.append((xyz, src))
         return n_upon.value, out
+
+    def chain_sums(self, values):
+        """Sequential float32 sums of the rows of `values` (chains x n) by exact_sum.hpp; returns (sums, stats)."""
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        if v.ndim == 1:
+            v = v[None, :]
+        sums = np.zeros(v.shape[0], np.float32)
+        stats = np.zeros(4, np.uint32)
+        self._check(self.lib.fn["debug_chain_sums"](self._h, v.ctypes.data, v.shape[1], v.shape[0], sums.ctypes.data,
+                                                    stats.ctypes.data), "debug_chain_sums")
+        return sums, dict(zip(("slow_blocks", "float_steps", "plain_blocks", "top_hits"), (int(x) for x in stats)))
+
+    def xs_stats(self):
+        stats = np.zeros(4, np.uint32)
+        self._check(self.lib.fn["debug_xs_stats"](self._h, stats.ctypes.data), "debug_xs_stats")
+        return dict(zip(("slow_blocks", "float_steps", "plain_blocks", "top_hits"), (int(x) for x in stats)))
 
     def fast_division_active(self):
         return self.lib.fn["fast_division_active"](self._h)

@@ -22,6 +22,7 @@
 #include "upon_plane.hpp"
 #include "voxel_rank.hpp"
 #include "hull.hpp"
+#include "verify_big.hpp"
 
 using namespace hope;
 
@@ -191,6 +192,9 @@ struct hope_ctx {
   long long n_raw_override = -1;
   unsigned knn_fine_limit = 4096;  // more left-over k-NN queries than this build the coarse index (test knob)
   unsigned n_knn_todo = 0;
+  int verify_big_from = 32768;     // clusters of this many members and more are verified by verify_big.hpp
+                                   // (HOPE_DEBUG_VERIFY_BIG=n: test knob; 0 = never)
+  xs::Stats* d_xs_stats = nullptr; // counters of the exact-sum chains of the last call (hope_debug_xs_stats)
   int force_ieee_div = 0;     // test knob HOPE_DEBUG_IEEE_DIV
   int fast_div = 0;           // div_const<true> verified for fast_div_key (the current camera model)
   float fast_div_key[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -701,6 +705,70 @@ int stage_voxel(hope_ctx* c, const Src& src, size_t n_per_frame, int cell_bits, 
   return HOPE_OK;
 }
 
+// A10..A12 of the clusters of big_from members and more (verify_big.hpp): exact_sum.hpp's integer blocks in
+// place of the chain of dependent adds.
+int verify_big(hope_ctx* c, unsigned n_cl, unsigned n_big, unsigned n_sb, int big_from, const uint32_t* members,
+               const uint32_t* cl_first, const float4* fit_pt, const float4* fit_nrm, ClusterRec* rec)
+{
+  hipStream_t s = c->stream;
+  const size_t n_el = (size_t)n_sb * xs::kSuper, n_blk = (size_t)n_sb * xs::kSub;
+  unsigned* cursor;
+  xs::Span* spans;
+  BigInfo* info;
+  unsigned* sb_owner;
+  BigState* state;
+  float *terms, *spred, *sums;
+  double* bsum;
+  xs::RecA *recA, *topA;
+  int *recB, *topB;
+  ALLOC(cursor, unsigned, 2);
+  ALLOC(spans, xs::Span, n_big);
+  ALLOC(info, BigInfo, n_big);
+  ALLOC(sb_owner, unsigned, n_sb);
+  ALLOC(state, BigState, n_big);
+  ALLOC(terms, float, 6 * n_el);
+  ALLOC(bsum, double, 6 * n_blk);
+  ALLOC(spred, float, 6 * n_blk);
+  ALLOC(recA, xs::RecA, 6 * n_blk);
+  ALLOC(recB, int, 6 * n_blk);
+  ALLOC(topA, xs::RecA, 6 * (size_t)n_sb);
+  ALLOC(topB, int, 6 * (size_t)n_sb);
+  ALLOC(sums, float, (size_t)n_big * kBigSums);
+  if (!c->d_xs_stats) {
+    if (hipMalloc((void**)&c->d_xs_stats, sizeof(xs::Stats)) != hipSuccess) {
+      (void)hipGetLastError();
+      c->d_xs_stats = nullptr;
+    }
+  }
+  if (c->d_xs_stats) HIPCHK(hipMemsetAsync(c->d_xs_stats, 0, sizeof(xs::Stats), s));
+  HIPCHK(hipMemsetAsync(cursor, 0, 2 * sizeof(unsigned), s));
+  HIPCHK(hipMemsetAsync(sums, 0, sizeof(float) * (size_t)n_big * kBigSums, s));
+  hipLaunchKernelGGL(k_big_list, dim3(nblk(n_cl)), dim3(kBlock), 0, s, rec, n_cl, big_from, cursor, spans, info, sb_owner,
+                     state);
+  auto sums_of = [&](int n_chains, int sum_off) {
+    hipLaunchKernelGGL(xs::k_xs_scan, dim3(n_big, n_chains), dim3(256), 0, s, spans, bsum, n_blk, spred);
+    hipLaunchKernelGGL(xs::k_xs_records, dim3(n_sb, n_chains), dim3(256), 0, s, terms, n_el, spred, n_blk, recA, recB,
+                       topA, topB, (size_t)n_sb);
+    hipLaunchKernelGGL(xs::k_xs_chain, dim3(n_big, n_chains), dim3(64), 0, s, spans, terms, n_el, recA, recB, n_blk, topA,
+                       topB, (size_t)n_sb, sums + sum_off, kBigSums, &state[0].alive,
+                       (int)(sizeof(BigState) / sizeof(int)), c->d_xs_stats);
+  };
+  const dim3 gt(n_sb), gg(nblk(n_big));
+  hipLaunchKernelGGL(k_big_terms<1>, gt, dim3(kBlock), 0, s, spans, info, sb_owner, state, members, cl_first, fit_pt,
+                     fit_nrm, terms, n_el, bsum, n_blk);
+  sums_of(4, 0);
+  hipLaunchKernelGGL(k_big_gate<1>, gg, dim3(kBlock), 0, s, info, n_big, state, sums, c->th_angle, rec);
+  hipLaunchKernelGGL(k_big_terms<2>, gt, dim3(kBlock), 0, s, spans, info, sb_owner, state, members, cl_first, fit_pt,
+                     fit_nrm, terms, n_el, bsum, n_blk);
+  sums_of(3, 4);
+  hipLaunchKernelGGL(k_big_gate<2>, gg, dim3(kBlock), 0, s, info, n_big, state, sums, c->th_angle, rec);
+  hipLaunchKernelGGL(k_big_terms<3>, gt, dim3(kBlock), 0, s, spans, info, sb_owner, state, members, cl_first, fit_pt,
+                     fit_nrm, terms, n_el, bsum, n_blk);
+  sums_of(6, 8);
+  hipLaunchKernelGGL(k_big_gate<3>, gg, dim3(kBlock), 0, s, info, n_big, state, sums, c->th_angle, rec);
+  return HOPE_OK;
+}
+
 template <class CK>
 int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2_bits)
 {
@@ -1028,9 +1096,19 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   HIPCHK(exclusive_scan_u32x3(pa, seg_flags, seg_scan, (size_t)n_fit + 1, s));
   hipLaunchKernelGGL(k_frame_cluster_ranges, dim3(nblk(F)), dim3(kBlock), 0, s, c->d_fi, F, seg_scan);
   prof_close(c, ST_SEGMENTS, pm, (4.0 + 4.0 + 4.0 + 7 * 4.0) * n_fit);
-  HIPCHK(hipMemcpyAsync(h_cnt, &seg_scan[n_fit].b, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
+  // the cluster count comes back together with the number of large clusters and their super blocks
+  const int big_from = c->verify_big_from > 0 ? std::max(c->verify_big_from, 3) : INT_MAX;
+  HIPCHK(hipMemsetAsync(&c->d_glob->n_big, 0, 2 * sizeof(unsigned), s));
+  if (max_fit >= (unsigned)big_from)
+    hipLaunchKernelGGL(k_big_count, dim3(nblk((size_t)n_fit + 1)), dim3(kBlock), 0, s, cnt, seg_flags, n_fit + 1,
+                       big_from, c->d_glob);
+  HIPCHK(hipMemcpyAsync(&c->d_glob->pad, &seg_scan[n_fit].b, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+  {
+    int st = sync_globals(c);
+    if (st != HOPE_OK) return st;
+  }
   const unsigned n_cl = *h_cnt;
+  const unsigned n_big = c->h_glob->n_big, n_big_sb = c->h_glob->n_big_sb;
   c->n_cl_total = n_cl;
 
   int* cid;
@@ -1059,12 +1137,12 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
     // a cluster holds points of one frame, so max_fit bounds its size: depth batches never take the second launch.
     // A floor or a wall gets longer tiles (more LDS per workgroup, so for these alone); running the two launches
     // side by side on two streams was measured and gains nothing over one after the other
-    const bool big = max_fit >= (unsigned)kVBigFrom;
     hipLaunchKernelGGL(k_cluster_verify_b<kVTile>, dim3(n_cl), dim3(kBlock), 0, s, members, cl_first, fit_pt, fit_nrm,
-                       n_cl, c->th_angle, 0, big ? kVBigFrom : INT_MAX, rec);
-    if (big)
-      hipLaunchKernelGGL(k_cluster_verify_b<kVTileBig>, dim3(n_cl), dim3(kBlock), 0, s, members, cl_first, fit_pt,
-                         fit_nrm, n_cl, c->th_angle, kVBigFrom, INT_MAX, rec);
+                       n_cl, c->th_angle, 0, big_from, rec);
+    if (n_big > 0) {
+      int st = verify_big(c, n_cl, n_big, n_big_sb, big_from, members, cl_first, fit_pt, fit_nrm, rec);
+      if (st != HOPE_OK) return st;
+    }
     prof_close(c, ST_VERIFY, pm, (4.0 + 16.0 + 16.0) * n_fit + 32.0 * n_cl);
     c->h_rec.resize(n_cl);
     HIPCHK(hipMemcpyAsync(c->h_rec.data(), rec, sizeof(ClusterRec) * n_cl, hipMemcpyDeviceToHost, s));
@@ -1364,6 +1442,8 @@ HOPE_API int hope_create(const hope_config* cfg, hope_ctx** out)
     c->normals_direct = std::strcmp(knob, "tiles-knn") == 0 ? 1 : 0;
     c->knn_direct = std::strcmp(knob, "tiles-normals") == 0 ? 1 : 0;
   }
+  knob = std::getenv("HOPE_DEBUG_VERIFY_BIG");
+  if (knob) c->verify_big_from = std::atoi(knob);
   knob = std::getenv("HOPE_DEBUG_VOXEL_RANK");
   c->voxel_rank = (knob && knob[0] == '0') ? 0 : c->seg_sort;
   *out = c;
@@ -1379,6 +1459,7 @@ HOPE_API void hope_destroy(hope_ctx* c)
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->arena.release();
   if (c->d_glob) (void)hipFree(c->d_glob);
+  if (c->d_xs_stats) (void)hipFree(c->d_xs_stats);
   if (c->h_glob) (void)hipHostFree(c->h_glob);
   for (hipEvent_t e : c->prof.ev) (void)hipEventDestroy(e);
   if (c->ev_a) (void)hipEventDestroy(c->ev_a);
@@ -2426,6 +2507,76 @@ HOPE_API int hope_profile_enable(hope_ctx* c, int on)
     c->prof.launches[i] = 0;
   }
   for (hope_ctx* k : c->kids) hope_profile_enable(k, on);
+  return HOPE_OK;
+}
+
+// Instrumentation / test access to exact_sum.hpp: the sequential fp32 sums of n_chains arrays of n host floats
+// (chain-major), evaluated the way verify_big.hpp evaluates a cluster's sums.  stats (may be null): blocks the
+// wave had to evaluate itself, single float steps inside them, blocks finished by plain adds, super-block records
+// applied.
+HOPE_API int hope_debug_chain_sums(hope_ctx* c, const float* values, size_t n, int n_chains, float* sums,
+                                   uint32_t stats[4])
+{
+  if (!c || !values || !sums || n_chains < 1 || n_chains > 64 || n == 0 || n > ((size_t)1 << 30)) return HOPE_E_INVALID;
+  if (hipSetDevice(c->cfg.device) != hipSuccess) return HOPE_E_HIP;
+  ArenaScope scope(c->arena);
+  hipStream_t s = c->stream;
+  const unsigned n_sb = (unsigned)((n + xs::kSuper - 1) / xs::kSuper);
+  const size_t n_el = (size_t)n_sb * xs::kSuper, n_blk = (size_t)n_sb * xs::kSub;
+  float *terms, *spred, *d_sums;
+  double* bsum;
+  xs::RecA *recA, *topA;
+  int *recB, *topB;
+  xs::Span* span;
+  xs::Stats* d_stats;
+  ALLOC(terms, float, n_chains * n_el);
+  ALLOC(bsum, double, n_chains * n_blk);
+  ALLOC(spred, float, n_chains * n_blk);
+  ALLOC(recA, xs::RecA, n_chains * n_blk);
+  ALLOC(recB, int, n_chains * n_blk);
+  ALLOC(topA, xs::RecA, (size_t)n_chains * n_sb);
+  ALLOC(topB, int, (size_t)n_chains * n_sb);
+  ALLOC(d_sums, float, n_chains);
+  ALLOC(span, xs::Span, 1);
+  ALLOC(d_stats, xs::Stats, 1);
+  const xs::Span h_span{0u, n_sb};
+  HIPCHK(hipMemsetAsync(terms, 0, sizeof(float) * n_chains * n_el, s));
+  HIPCHK(hipMemsetAsync(d_stats, 0, sizeof(xs::Stats), s));
+  HIPCHK(hipMemcpyAsync(span, &h_span, sizeof(h_span), hipMemcpyHostToDevice, s));
+  for (int q = 0; q < n_chains; ++q)
+    HIPCHK(hipMemcpyAsync(terms + q * n_el, values + (size_t)q * n, sizeof(float) * n, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(xs::k_xs_blocksums, dim3(n_sb, n_chains), dim3(256), 0, s, terms, n_el, bsum, n_blk);
+  hipLaunchKernelGGL(xs::k_xs_scan, dim3(1, n_chains), dim3(256), 0, s, span, bsum, n_blk, spred);
+  hipLaunchKernelGGL(xs::k_xs_records, dim3(n_sb, n_chains), dim3(256), 0, s, terms, n_el, spred, n_blk, recA, recB, topA,
+                     topB, (size_t)n_sb);
+  hipLaunchKernelGGL(xs::k_xs_chain, dim3(1, n_chains), dim3(64), 0, s, span, terms, n_el, recA, recB, n_blk, topA, topB,
+                     (size_t)n_sb, d_sums, n_chains, (const int*)nullptr, 0, d_stats);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(sums, d_sums, sizeof(float) * n_chains, hipMemcpyDeviceToHost, s));
+  xs::Stats h_stats{};
+  HIPCHK(hipMemcpyAsync(&h_stats, d_stats, sizeof(h_stats), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (stats) {
+    stats[0] = h_stats.slow_blocks;
+    stats[1] = h_stats.float_steps;
+    stats[2] = h_stats.plain_blocks;
+    stats[3] = h_stats.top_hits;
+  }
+  return HOPE_OK;
+}
+// the same counters for the large clusters of the last segment call (all zero if none took that path)
+HOPE_API int hope_debug_xs_stats(hope_ctx* c, uint32_t stats[4])
+{
+  if (!c || !stats) return HOPE_E_INVALID;
+  xs::Stats h{};
+  if (c->d_xs_stats) {
+    if (hipSetDevice(c->cfg.device) != hipSuccess) return HOPE_E_HIP;
+    HIPCHK(hipMemcpy(&h, c->d_xs_stats, sizeof(h), hipMemcpyDeviceToHost));
+  }
+  stats[0] = h.slow_blocks;
+  stats[1] = h.float_steps;
+  stats[2] = h.plain_blocks;
+  stats[3] = h.top_hits;
   return HOPE_OK;
 }
 

@@ -61,6 +61,8 @@ struct Globals {  // scalars produced on device, read back at the sync points
   unsigned int code_overflow;  // k_bbox_records: a cell lies outside the packed code range
   unsigned int rank_overflow;  // k_voxel_rank: a frame has more voxels than the LDS counters hold
   unsigned int max_vox;        // k_frame_vox_scan: largest per-frame count of voxels
+  unsigned int n_big;          // k_big_count: clusters of verify_big_from members and more ...
+  unsigned int n_big_sb;       // ... and their 1024-member super blocks (verify_big.hpp)
 };
 
 struct DepthSrc {
@@ -1890,6 +1892,42 @@ __device__ inline void principal_axis_2x2(float a, float b, float d, float& ax, 
   ay = vy / nrm;
 }
 
+// The scalar steps of Utilities::normalAnalysis between its sums (utilities.cpp:151-255), shared by the two
+// kernels that evaluate the sums (k_cluster_verify_b: chains; verify_big.hpp: exact integer blocks).
+// (i)-(ii): mean vector and its tilt; false = the cluster fails here
+__device__ __forceinline__ bool verify_mean_gate(int sz, float s0, float s1, float s2, float th_angle, float& m0,
+                                                 float& m1)
+{
+  if (sz <= 2) return false;
+  const float fsz = (float)sz;
+  m0 = s0 / fsz;
+  m1 = s1 / fsz;
+  const float m2 = s2 / fsz;
+  const float proj_norm = __builtin_sqrtf(m0 * m0 + m1 * m1);
+  const float mean_norm = __builtin_sqrtf(m0 * m0 + (m1 * m1 + m2 * m2));
+  const float grad = hope_det_asinf(proj_norm / mean_norm);
+  return !(grad > th_angle);
+}
+// (iii): principal axis of the normals' xy covariance
+__device__ __forceinline__ void verify_axis(int sz, float sxx, float sxy, float syy, float& ax, float& ay)
+{
+  const float denom = (float)(sz - 1);
+  principal_axis_2x2(sxx / denom, sxy / denom, syy / denom, ax, ay);
+}
+// (iv)-(v): the two halves' mean normals and the angle between them
+__device__ __forceinline__ int verify_split(const float* s6, unsigned na, unsigned nb, float th_angle)
+{
+  if (na == 0 || nb == 0) return 0;
+  const float fa = (float)na, fb = (float)nb;
+  const float p1[3] = {s6[0] / fa, s6[1] / fa, s6[2] / fa};
+  const float p2[3] = {s6[3] / fb, s6[4] / fb, s6[5] / fb};
+  const float mu = p2[0] * p1[0] + (p2[1] * p1[1] + p2[2] * p1[2]);
+  const float n1 = __builtin_sqrtf(sqnorm3(p1));
+  const float n2 = __builtin_sqrtf(sqnorm3(p2));
+  const float rad_mu = hope_det_acosf(mu / (n1 * n2));
+  return (rad_mu <= th_angle) ? 1 : 0;
+}
+
 // ---- K10: A10 mean z (utilities.cpp:751-769), A12 bbox (plane_segment.cpp:408-420),
 // A11 normalAnalysis (utilities.cpp:151-282).  Every sum is the reference's sequential float sum
 // over the members in ascending index.
@@ -2093,61 +2131,42 @@ k_cluster_verify_b(const uint32_t* members, const uint32_t* cl_first, const floa
   const float mid = s_bc[0], s0 = s_bc[1], s1 = s_bc[2], s2 = s_bc[3];
 
   int pass = 0;
-  if (sz > 2) {
-    const float fsz = (float)sz;
-    const float m0 = s0 / fsz, m1 = s1 / fsz, m2 = s2 / fsz;
-    const float proj_norm = __builtin_sqrtf(m0 * m0 + m1 * m1);
-    const float mean_norm = __builtin_sqrtf(m0 * m0 + (m1 * m1 + m2 * m2));
-    const float grad = hope_det_asinf(proj_norm / mean_norm);
-    if (!(grad > th_angle)) {  // block-uniform
-      // ---- pass 2: covariance sums cxx, cxy, cyy (lanes 0..2) ---------------------------------
-      const float cacc =
-          verify_pass<kVTile, false>(m, sz, fit_pt, fit_nrm, s_v, 3, [&](const float4&, const float4& nn, float* slot) {
-            const float tx = nn.x - m0, ty = nn.y - m1;
-            slot[0 * kVStride] = tx * tx;
-            slot[1 * kVStride] = tx * ty;
-            slot[2 * kVStride] = ty * ty;
-          });
-      __syncthreads();
-      if (chain_wave && lane < 3) s_bc[lane] = cacc;
-      __syncthreads();
-      const float denom = (float)(sz - 1);
-      const float cxx = s_bc[0] / denom;
-      const float cxy = s_bc[1] / denom;
-      const float cyy = s_bc[2] / denom;
-      float ax, ay;
-      principal_axis_2x2(cxx, cxy, cyy, ax, ay);
-      // ---- pass 3: split sums; lanes 0..2 own part 1 (nx, ny, |nz|), lanes 3..5 part 2 ----------
-      unsigned na = 0;
-      const float pacc =
-          verify_pass<kVTile, false>(m, sz, fit_pt, fit_nrm, s_v, 6, [&](const float4&, const float4& nn, float* slot) {
-            const float tx = nn.x - m0, ty = nn.y - m1;
-            const bool side = (ax * tx + ay * ty > 0.f);
-            const float nz = fabsf(nn.z);
-            slot[0 * kVStride] = side ? nn.x : 0.f;
-            slot[1 * kVStride] = side ? nn.y : 0.f;
-            slot[2 * kVStride] = side ? nz : 0.f;
-            slot[3 * kVStride] = side ? 0.f : nn.x;
-            slot[4 * kVStride] = side ? 0.f : nn.y;
-            slot[5 * kVStride] = side ? 0.f : nz;
-            na += side ? 1u : 0u;
-          });
-      na = block_sum_u32(na, s_cnt);
-      __syncthreads();
-      if (chain_wave && lane < 6) s_bc[lane] = pacc;
-      __syncthreads();
-      const unsigned nb = (unsigned)sz - na;
-      if (na != 0 && nb != 0) {
-        const float fa = (float)na, fb = (float)nb;
-        const float p1[3] = {s_bc[0] / fa, s_bc[1] / fa, s_bc[2] / fa};
-        const float p2[3] = {s_bc[3] / fb, s_bc[4] / fb, s_bc[5] / fb};
-        const float mu = p2[0] * p1[0] + (p2[1] * p1[1] + p2[2] * p1[2]);
-        const float n1 = __builtin_sqrtf(sqnorm3(p1));
-        const float n2 = __builtin_sqrtf(sqnorm3(p2));
-        const float rad_mu = hope_det_acosf(mu / (n1 * n2));
-        pass = (rad_mu <= th_angle) ? 1 : 0;
-      }
-    }
+  float m0 = 0.f, m1 = 0.f;
+  if (verify_mean_gate(sz, s0, s1, s2, th_angle, m0, m1)) {  // block-uniform
+    // ---- pass 2: covariance sums cxx, cxy, cyy (lanes 0..2) ---------------------------------
+    const float cacc =
+        verify_pass<kVTile, false>(m, sz, fit_pt, fit_nrm, s_v, 3, [&](const float4&, const float4& nn, float* slot) {
+          const float tx = nn.x - m0, ty = nn.y - m1;
+          slot[0 * kVStride] = tx * tx;
+          slot[1 * kVStride] = tx * ty;
+          slot[2 * kVStride] = ty * ty;
+        });
+    __syncthreads();
+    if (chain_wave && lane < 3) s_bc[lane] = cacc;
+    __syncthreads();
+    float ax, ay;
+    verify_axis(sz, s_bc[0], s_bc[1], s_bc[2], ax, ay);
+    // ---- pass 3: split sums; lanes 0..2 own part 1 (nx, ny, |nz|), lanes 3..5 part 2 ----------
+    unsigned na = 0;
+    const float pacc =
+        verify_pass<kVTile, false>(m, sz, fit_pt, fit_nrm, s_v, 6, [&](const float4&, const float4& nn, float* slot) {
+          const float tx = nn.x - m0, ty = nn.y - m1;
+          const bool side = (ax * tx + ay * ty > 0.f);
+          const float nz = fabsf(nn.z);
+          slot[0 * kVStride] = side ? nn.x : 0.f;
+          slot[1 * kVStride] = side ? nn.y : 0.f;
+          slot[2 * kVStride] = side ? nz : 0.f;
+          slot[3 * kVStride] = side ? 0.f : nn.x;
+          slot[4 * kVStride] = side ? 0.f : nn.y;
+          slot[5 * kVStride] = side ? 0.f : nz;
+          na += side ? 1u : 0u;
+        });
+    na = block_sum_u32(na, s_cnt);
+    __syncthreads();
+    if (chain_wave && lane < 6) s_bc[lane] = pacc;
+    __syncthreads();
+    const float s6[6] = {s_bc[0], s_bc[1], s_bc[2], s_bc[3], s_bc[4], s_bc[5]};
+    pass = verify_split(s6, na, (unsigned)sz - na, th_angle);
   }
   if (tid == 0) {
     rec[c].z_mean = mid / (float)ctz;

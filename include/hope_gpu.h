@@ -309,6 +309,17 @@ HOPE_API int hope_profile_stage(hope_ctx* ctx, int stage, const char** name, dou
  * the sizes of the calls made while enabled) moved by the same timed regions */
 HOPE_API int hope_profile_stage_bytes(hope_ctx* ctx, int stage, double* alg_bytes);
 
+/* The sequential fp32 sums s = fl(fl(a0 + a1) + a2 ...) of n_chains arrays of n host floats (values: chain-major),
+ * evaluated the way the library evaluates the reference's sequential sums over a large cluster (getCloudZInfo
+ * utilities.cpp:751-769, calNormalMean :257-282, normalAnalysis :151-255): in parallel, in integer arithmetic
+ * per binade, bit-identical to the chain of float adds (hope_amd/csrc/exact_sum.hpp).  Test access; stats (may be
+ * NULL): {blocks of 64 the wave evaluated itself, single float adds inside them, blocks finished by plain
+ * sequential adds, 1024-member records applied}. */
+HOPE_API int hope_debug_chain_sums(hope_ctx* ctx, const float* values, size_t n, int n_chains, float* sums,
+                                   uint32_t stats[4]);
+/* the same counters for the large clusters of the last segment call */
+HOPE_API int hope_debug_xs_stats(hope_ctx* ctx, uint32_t stats[4]);
+
 /* 1 if the last depth call used the 3-instruction division by the camera constants (it is
  * enabled only after an exhaustive on-device comparison with the IEEE quotient for every
  * dividend the camera model can produce), 0 if it used IEEE divisions */

@@ -152,6 +152,39 @@ def test_one_huge_cluster(hip_lib, oracle_lib):
     assert g.clusters(0)["size"].max() > 40000 and g.counts(0).n_planes >= 1
 
 
+def test_large_cluster_sums_by_integer_blocks(hip_lib, oracle_lib, monkeypatch, tum_example):
+    """verify_big.hpp / exact_sum.hpp: every cluster of 64 members and more takes the path that the floors of
+    configs 3 and 4 take (HOPE_DEBUG_VERIFY_BIG lowers its threshold from 32768), on depth frames, a cloud with
+    walls and clutter and a floor; HOPE_DEBUG_VERIFY_BIG=0 keeps every cluster on the chain kernel."""
+    from hope_amd import synth
+    depth, t, q = synth_frames(6, first=40)
+    cloud = synth.make_multilevel_cloud(400000, first_index=777, device="cpu").numpy()
+    rng = np.random.default_rng(6)
+    n = 500000
+    floor = np.concatenate([rng.uniform(-5, 5, (n, 2)), rng.normal(0.0, 0.002, (n, 1))], 1).astype(np.float32)
+    o = HopeContext(oracle_lib)
+    for knob in ("64", "3", "0"):
+        monkeypatch.setenv("HOPE_DEBUG_VERIFY_BIG", knob)
+        g = HopeContext(hip_lib)
+        monkeypatch.delenv("HOPE_DEBUG_VERIFY_BIG")
+        for c in (g, o):
+            c.set_frame_poses(t, q)
+            assert c.segment_depth(depth) == 0
+        for f in range(6):
+            assert_frame_equal(o, g, f)
+        st = g.xs_stats()
+        assert (st["top_hits"] > 0) == (knob != "0"), st
+        for xyz in (cloud, floor):
+            for c in (g, o):
+                assert c.segment_cloud(xyz) == 0
+            assert_frame_equal(o, g, 0)
+        d, tt, qq = tum_example
+        for c in (g, o):
+            c.set_pose(tt, qq)
+            assert c.segment_depth(d) == 0
+        assert_frame_equal(o, g, 0)
+
+
 def test_rt_mode_and_height_window(hip_lib, oracle_lib):
     z = np.load(os.path.join(GOLDEN, "synth_frames_0_2.npz"))
     g, o = both(hip_lib, oracle_lib, mode=HOPE_MODE_RT, min_height=0.6, max_height=0.9)
