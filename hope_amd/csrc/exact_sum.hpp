@@ -116,15 +116,19 @@ __device__ __forceinline__ int lane_q(bool use, int I, bool up, bool tie, int p_
   return use ? q : 0;
 }
 
+// inclusive prefix sum over the 64 lanes with data-parallel-primitive moves (seven adds; a shuffle through the
+// LDS crossbar per step costs the chain's slow path ten times as much)
 __device__ __forceinline__ int wave_incl_scan(int v)
 {
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(v, o);
-    if (lane >= o) v += t;
-  }
-  return v;
+  int x = v;
+  x += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);  // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, v, 0x113, 0xf, 0xf, true);  // row_shr:3   -> sums of 4 within a row of 16
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xe, true);  // row_shr:4   -> sums of 8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xc, true);  // row_shr:8   -> inclusive within the row
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
+  return x;
 }
 __device__ __forceinline__ int wave_min(int v)
 {
@@ -181,21 +185,28 @@ struct Span {
   unsigned sb_off;  // first super block
   unsigned n_sb;    // super blocks
 };
-// grid (n_spans, n_chains), 256 threads
+// grid (n_spans, n_chains), 256 threads; a thread owns the sixteen block sums of one super block
 __global__ void __launch_bounds__(256) k_xs_scan(const Span* spans, const double* bsum, size_t bsum_stride, float* spred)
 {
   __shared__ double s_w[4];
   __shared__ double s_carry;
   const Span sp = spans[blockIdx.x];
   const size_t base = blockIdx.y * bsum_stride + (size_t)sp.sb_off * kSub;
-  const unsigned nb = sp.n_sb * kSub;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (threadIdx.x == 0) s_carry = 0.0;
   __syncthreads();
-  for (unsigned b0 = 0; b0 < nb; b0 += 256) {
-    const unsigned b = b0 + threadIdx.x;
-    const double v = b < nb ? bsum[base + b] : 0.0;
-    double inc = v;
+  for (unsigned sb0 = 0; sb0 < sp.n_sb; sb0 += 256) {
+    const unsigned sb = sb0 + threadIdx.x;
+    double v[kSub];
+    double tot = 0.0;
+    if (sb < sp.n_sb) {
+#pragma unroll
+      for (int k = 0; k < kSub; ++k) {
+        v[k] = bsum[base + (size_t)sb * kSub + k];
+        tot += v[k];
+      }
+    }
+    double inc = tot;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const double t = __shfl_up(inc, o);
@@ -205,7 +216,14 @@ __global__ void __launch_bounds__(256) k_xs_scan(const Span* spans, const double
     __syncthreads();
     double pre = s_carry;
     for (int i = 0; i < w; ++i) pre += s_w[i];
-    if (b < nb) spred[base + b] = (float)(pre + (inc - v));
+    if (sb < sp.n_sb) {
+      double run = pre + (inc - tot);
+#pragma unroll
+      for (int k = 0; k < kSub; ++k) {
+        spred[base + (size_t)sb * kSub + k] = (float)run;
+        run += v[k];
+      }
+    }
     __syncthreads();
     if (threadIdx.x == 255) s_carry = pre + inc;
     __syncthreads();
@@ -374,7 +392,11 @@ __global__ void __launch_bounds__(64) k_xs_chain(const Span* spans, const float*
                                                  const int* topB, size_t top_stride, float* out, int out_stride,
                                                  const int* alive, int alive_stride, Stats* stats)
 {
-  __shared__ float s_t[kSuper];  // the terms of a super block whose record did not apply
+  if (stats) stats += blockIdx.y & 7;  // (instrumentation: per chain, eight slots)
+  // the terms of a super block whose record did not apply.  Such super blocks come in runs (a sum that hovers
+  // around a power of two), so while one is evaluated the next one's records and terms are already on their
+  // way into the other buffer: one exposed round trip to memory per run instead of one per super block.
+  __shared__ float s_t[2][kSuper];
   const Span sp = spans[blockIdx.x];
   const int lane = threadIdx.x;
   if (alive && !alive[(size_t)blockIdx.x * alive_stride]) {
@@ -391,6 +413,24 @@ __global__ void __launch_bounds__(64) k_xs_chain(const Span* spans, const float*
   st.S = 0;
   st.s = 0.f;
   unsigned hits = 0;
+  unsigned have = 0xffffffffu;  // super block whose data the registers below hold (fetched, maybe still in flight)
+  RecA br;
+  int br_hi = 0;
+  float tv[kSub];
+  br.e = kInvalid;
+  br.q0 = br.q1 = br.lo = 0;
+#pragma unroll
+  for (int k = 0; k < kSub; ++k) tv[k] = 0.f;
+  auto fetch = [&](unsigned sbi) {
+    const size_t b0 = (size_t)sbi * kSub;
+    if (lane < kSub) {
+      br = ra[b0 + lane];
+      br_hi = rb[b0 + lane];
+    }
+#pragma unroll
+    for (int k = 0; k < kSub; ++k) tv[k] = t[(b0 + k) * kBlk + lane];
+    have = sbi;
+  };
   for (unsigned t0 = 0; t0 < sp.n_sb; t0 += 64) {
     const unsigned n_here = min(64u, sp.n_sb - t0);
     RecA mine;
@@ -408,30 +448,23 @@ __global__ void __launch_bounds__(64) k_xs_chain(const Span* spans, const float*
         ++hits;
         continue;
       }
-      // the super block's sixteen blocks one by one; its records and terms are fetched together (one
-      // round trip to memory instead of one per block that needs its terms)
-      const size_t b0 = (size_t)(t0 + i) * kSub;
-      RecA br;
-      int br_hi = 0;
-      br.e = kInvalid;
-      br.q0 = br.q1 = br.lo = 0;
-      if (lane < kSub) {
-        br = ra[b0 + lane];
-        br_hi = rb[b0 + lane];
-      }
-      float tv[kSub];
-#pragma unroll
-      for (int k = 0; k < kSub; ++k) tv[k] = t[(b0 + k) * kBlk + lane];
+      // the super block's sixteen blocks one by one
+      const unsigned sbi = t0 + i;
+      if (have != sbi) fetch(sbi);
+      float* buf = s_t[sbi & 1];
+      const RecA cr = br;
+      const int cr_hi = br_hi;
       __syncthreads();  // (one wave: orders the LDS accesses for the compiler, costs nothing)
 #pragma unroll
-      for (int k = 0; k < kSub; ++k) s_t[k * kBlk + lane] = tv[k];
+      for (int k = 0; k < kSub; ++k) buf[k * kBlk + lane] = tv[k];
       __syncthreads();
+      if (sbi + 1 < sp.n_sb) fetch(sbi + 1);  // lands while this one is evaluated
       for (int k = 0; k < kSub; ++k) {
-        if (apply(st, __builtin_amdgcn_readlane(br.e, k), __builtin_amdgcn_readlane(br.q0, k),
-                  __builtin_amdgcn_readlane(br.q1, k), __builtin_amdgcn_readlane(br.lo, k),
-                  __builtin_amdgcn_readlane(br_hi, k)))
+        if (apply(st, __builtin_amdgcn_readlane(cr.e, k), __builtin_amdgcn_readlane(cr.q0, k),
+                  __builtin_amdgcn_readlane(cr.q1, k), __builtin_amdgcn_readlane(cr.lo, k),
+                  __builtin_amdgcn_readlane(cr_hi, k)))
           continue;
-        slow_block(st, s_t[k * kBlk + lane], stats);
+        slow_block(st, buf[k * kBlk + lane], stats);
       }
     }
   }

@@ -715,7 +715,7 @@ int verify_big(hope_ctx* c, unsigned n_cl, unsigned n_big, unsigned n_sb, int bi
   unsigned* cursor;
   xs::Span* spans;
   BigInfo* info;
-  unsigned* sb_owner;
+  unsigned *sb_owner, *part;
   BigState* state;
   float *terms, *spred, *sums;
   double* bsum;
@@ -725,6 +725,7 @@ int verify_big(hope_ctx* c, unsigned n_cl, unsigned n_big, unsigned n_sb, int bi
   ALLOC(spans, xs::Span, n_big);
   ALLOC(info, BigInfo, n_big);
   ALLOC(sb_owner, unsigned, n_sb);
+  ALLOC(part, unsigned, 6 * (size_t)n_sb);
   ALLOC(state, BigState, n_big);
   ALLOC(terms, float, 6 * n_el);
   ALLOC(bsum, double, 6 * n_blk);
@@ -735,12 +736,12 @@ int verify_big(hope_ctx* c, unsigned n_cl, unsigned n_big, unsigned n_sb, int bi
   ALLOC(topB, int, 6 * (size_t)n_sb);
   ALLOC(sums, float, (size_t)n_big * kBigSums);
   if (!c->d_xs_stats) {
-    if (hipMalloc((void**)&c->d_xs_stats, sizeof(xs::Stats)) != hipSuccess) {
+    if (hipMalloc((void**)&c->d_xs_stats, 24 * sizeof(xs::Stats)) != hipSuccess) {
       (void)hipGetLastError();
       c->d_xs_stats = nullptr;
     }
   }
-  if (c->d_xs_stats) HIPCHK(hipMemsetAsync(c->d_xs_stats, 0, sizeof(xs::Stats), s));
+  if (c->d_xs_stats) HIPCHK(hipMemsetAsync(c->d_xs_stats, 0, 24 * sizeof(xs::Stats), s));
   HIPCHK(hipMemsetAsync(cursor, 0, 2 * sizeof(unsigned), s));
   HIPCHK(hipMemsetAsync(sums, 0, sizeof(float) * (size_t)n_big * kBigSums, s));
   hipLaunchKernelGGL(k_big_list, dim3(nblk(n_cl)), dim3(kBlock), 0, s, rec, n_cl, big_from, cursor, spans, info, sb_owner,
@@ -751,21 +752,21 @@ int verify_big(hope_ctx* c, unsigned n_cl, unsigned n_big, unsigned n_sb, int bi
                        topA, topB, (size_t)n_sb);
     hipLaunchKernelGGL(xs::k_xs_chain, dim3(n_big, n_chains), dim3(64), 0, s, spans, terms, n_el, recA, recB, n_blk, topA,
                        topB, (size_t)n_sb, sums + sum_off, kBigSums, &state[0].alive,
-                       (int)(sizeof(BigState) / sizeof(int)), c->d_xs_stats);
+                       (int)(sizeof(BigState) / sizeof(int)), c->d_xs_stats ? c->d_xs_stats + sum_off : nullptr);
   };
-  const dim3 gt(n_sb), gg(nblk(n_big));
+  const dim3 gt(n_sb), gg(n_big);
   hipLaunchKernelGGL(k_big_terms<1>, gt, dim3(kBlock), 0, s, spans, info, sb_owner, state, members, cl_first, fit_pt,
-                     fit_nrm, terms, n_el, bsum, n_blk);
+                     fit_nrm, terms, n_el, bsum, n_blk, part);
   sums_of(4, 0);
-  hipLaunchKernelGGL(k_big_gate<1>, gg, dim3(kBlock), 0, s, info, n_big, state, sums, c->th_angle, rec);
+  hipLaunchKernelGGL(k_big_gate<1>, gg, dim3(kWave), 0, s, spans, info, state, part, sums, c->th_angle, rec);
   hipLaunchKernelGGL(k_big_terms<2>, gt, dim3(kBlock), 0, s, spans, info, sb_owner, state, members, cl_first, fit_pt,
-                     fit_nrm, terms, n_el, bsum, n_blk);
+                     fit_nrm, terms, n_el, bsum, n_blk, part);
   sums_of(3, 4);
-  hipLaunchKernelGGL(k_big_gate<2>, gg, dim3(kBlock), 0, s, info, n_big, state, sums, c->th_angle, rec);
+  hipLaunchKernelGGL(k_big_gate<2>, gg, dim3(kWave), 0, s, spans, info, state, part, sums, c->th_angle, rec);
   hipLaunchKernelGGL(k_big_terms<3>, gt, dim3(kBlock), 0, s, spans, info, sb_owner, state, members, cl_first, fit_pt,
-                     fit_nrm, terms, n_el, bsum, n_blk);
+                     fit_nrm, terms, n_el, bsum, n_blk, part);
   sums_of(6, 8);
-  hipLaunchKernelGGL(k_big_gate<3>, gg, dim3(kBlock), 0, s, info, n_big, state, sums, c->th_angle, rec);
+  hipLaunchKernelGGL(k_big_gate<3>, gg, dim3(kWave), 0, s, spans, info, state, part, sums, c->th_angle, rec);
   return HOPE_OK;
 }
 
@@ -2538,10 +2539,10 @@ HOPE_API int hope_debug_chain_sums(hope_ctx* c, const float* values, size_t n, i
   ALLOC(topB, int, (size_t)n_chains * n_sb);
   ALLOC(d_sums, float, n_chains);
   ALLOC(span, xs::Span, 1);
-  ALLOC(d_stats, xs::Stats, 1);
+  ALLOC(d_stats, xs::Stats, 8);
   const xs::Span h_span{0u, n_sb};
   HIPCHK(hipMemsetAsync(terms, 0, sizeof(float) * n_chains * n_el, s));
-  HIPCHK(hipMemsetAsync(d_stats, 0, sizeof(xs::Stats), s));
+  HIPCHK(hipMemsetAsync(d_stats, 0, 8 * sizeof(xs::Stats), s));
   HIPCHK(hipMemcpyAsync(span, &h_span, sizeof(h_span), hipMemcpyHostToDevice, s));
   for (int q = 0; q < n_chains; ++q)
     HIPCHK(hipMemcpyAsync(terms + q * n_el, values + (size_t)q * n, sizeof(float) * n, hipMemcpyHostToDevice, s));
@@ -2553,14 +2554,17 @@ HOPE_API int hope_debug_chain_sums(hope_ctx* c, const float* values, size_t n, i
                      (size_t)n_sb, d_sums, n_chains, (const int*)nullptr, 0, d_stats);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(sums, d_sums, sizeof(float) * n_chains, hipMemcpyDeviceToHost, s));
-  xs::Stats h_stats{};
-  HIPCHK(hipMemcpyAsync(&h_stats, d_stats, sizeof(h_stats), hipMemcpyDeviceToHost, s));
+  xs::Stats h_stats[8] = {};
+  HIPCHK(hipMemcpyAsync(h_stats, d_stats, sizeof(h_stats), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   if (stats) {
-    stats[0] = h_stats.slow_blocks;
-    stats[1] = h_stats.float_steps;
-    stats[2] = h_stats.plain_blocks;
-    stats[3] = h_stats.top_hits;
+    stats[0] = stats[1] = stats[2] = stats[3] = 0;
+    for (const xs::Stats& h : h_stats) {
+      stats[0] += h.slow_blocks;
+      stats[1] += h.float_steps;
+      stats[2] += h.plain_blocks;
+      stats[3] += h.top_hits;
+    }
   }
   return HOPE_OK;
 }
@@ -2568,15 +2572,22 @@ HOPE_API int hope_debug_chain_sums(hope_ctx* c, const float* values, size_t n, i
 HOPE_API int hope_debug_xs_stats(hope_ctx* c, uint32_t stats[4])
 {
   if (!c || !stats) return HOPE_E_INVALID;
-  xs::Stats h{};
+  xs::Stats h[24] = {};
   if (c->d_xs_stats) {
     if (hipSetDevice(c->cfg.device) != hipSuccess) return HOPE_E_HIP;
-    HIPCHK(hipMemcpy(&h, c->d_xs_stats, sizeof(h), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(h, c->d_xs_stats, sizeof(h), hipMemcpyDeviceToHost));
   }
-  stats[0] = h.slow_blocks;
-  stats[1] = h.float_steps;
-  stats[2] = h.plain_blocks;
-  stats[3] = h.top_hits;
+  stats[0] = stats[1] = stats[2] = stats[3] = 0;
+  const bool show = std::getenv("HOPE_DEBUG_XS_PRINT") != nullptr;
+  for (int i = 0; i < 24; ++i) {
+    stats[0] += h[i].slow_blocks;
+    stats[1] += h[i].float_steps;
+    stats[2] += h[i].plain_blocks;
+    stats[3] += h[i].top_hits;
+    if (show && (h[i].slow_blocks || h[i].top_hits))
+      std::fprintf(stderr, "xs chain %2d: slow blocks %u, float steps %u, plain blocks %u, records applied %u\n", i,
+                   h[i].slow_blocks, h[i].float_steps, h[i].plain_blocks, h[i].top_hits);
+  }
   return HOPE_OK;
 }
 

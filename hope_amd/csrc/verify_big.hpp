@@ -99,8 +99,9 @@ template <int PASS>
 __global__ void __launch_bounds__(kBlock)
 k_big_terms(const xs::Span* spans, const BigInfo* info, const unsigned* sb_owner, BigState* state,
             const uint32_t* members, const uint32_t* cl_first, const float4* fit_pt, const float4* fit_nrm,
-            float* terms, size_t chain_stride, double* bsum, size_t bsum_stride)
+            float* terms, size_t chain_stride, double* bsum, size_t bsum_stride, unsigned* part)
 {
+  __shared__ unsigned s_part[kBlock / kWave][6];
   constexpr int kChains = PASS == 1 ? 4 : (PASS == 2 ? 3 : 6);
   const unsigned sb = blockIdx.x;
   const unsigned j = sb_owner[sb];
@@ -160,6 +161,8 @@ k_big_terms(const xs::Span* spans, const BigInfo* info, const unsigned* sb_owner
       if (lane == 0) bsum[q * bsum_stride + blk] = d;
     }
   }
+  // count, bounding box and split count of this super block (k_big_gate adds the super blocks up: thousands
+  // of atomics on one cluster's record would queue up behind each other)
   if (PASS == 1) {
     ct = wave_sum_u32(ct);
     mnx = wave_minmax(mnx, true);
@@ -167,27 +170,76 @@ k_big_terms(const xs::Span* spans, const BigInfo* info, const unsigned* sb_owner
     mxx = wave_minmax(mxx, false);
     mxy = wave_minmax(mxy, false);
     if (lane == 0) {
-      atomicAdd(&state[j].ct, ct);
-      atomicMin(&state[j].bb[0], f2ord(mnx));
-      atomicMin(&state[j].bb[1], f2ord(mny));
-      atomicMax(&state[j].bb[2], f2ord(mxx));
-      atomicMax(&state[j].bb[3], f2ord(mxy));
+      s_part[w][0] = ct;
+      s_part[w][1] = f2ord(mnx);
+      s_part[w][2] = f2ord(mny);
+      s_part[w][3] = f2ord(mxx);
+      s_part[w][4] = f2ord(mxy);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned r[5] = {s_part[0][0], s_part[0][1], s_part[0][2], s_part[0][3], s_part[0][4]};
+      for (int i = 1; i < kBlock / kWave; ++i) {
+        r[0] += s_part[i][0];
+        r[1] = min(r[1], s_part[i][1]);
+        r[2] = min(r[2], s_part[i][2]);
+        r[3] = max(r[3], s_part[i][3]);
+        r[4] = max(r[4], s_part[i][4]);
+      }
+      for (int i = 0; i < 5; ++i) part[(size_t)sb * 6 + i] = r[i];
     }
   } else if (PASS == 3) {
     na = wave_sum_u32(na);
-    if (lane == 0 && na) atomicAdd(&state[j].na, na);
+    if (lane == 0) s_part[w][5] = na;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(size_t)sb * 6 + 5] = s_part[0][5] + s_part[1][5] + s_part[2][5] + s_part[3][5];
   }
 }
 
-// One thread per large cluster: the scalar step between two passes (the same functions as k_cluster_verify_b).
+// One wave per large cluster: the scalar step between two passes (the same functions as k_cluster_verify_b),
+// after adding up what the super blocks counted.
 template <int PASS>
-__global__ void __launch_bounds__(kBlock)
-k_big_gate(const BigInfo* info, unsigned n_big, BigState* state, const float* sums, float th_angle, ClusterRec* rec)
+__global__ void __launch_bounds__(kWave)
+k_big_gate(const xs::Span* spans, const BigInfo* info, BigState* state, const unsigned* part, const float* sums,
+           float th_angle, ClusterRec* rec)
 {
-  const unsigned j = blockIdx.x * kBlock + threadIdx.x;
-  if (j >= n_big) return;
-  const float* s = sums + (size_t)j * kBigSums;
+  const unsigned j = blockIdx.x;
+  const int lane = threadIdx.x;
+  const xs::Span sp = spans[j];
   BigState& st = state[j];
+  if (PASS == 1) {
+    unsigned ct = 0, b0 = 0xffffffffu, b1 = 0xffffffffu, b2 = 0u, b3 = 0u;
+    for (unsigned i = lane; i < sp.n_sb; i += kWave) {
+      const unsigned* p = part + (size_t)(sp.sb_off + i) * 6;
+      ct += p[0];
+      b0 = min(b0, p[1]);
+      b1 = min(b1, p[2]);
+      b2 = max(b2, p[3]);
+      b3 = max(b3, p[4]);
+    }
+    ct = wave_sum_u32(ct);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      b0 = min(b0, (unsigned)__shfl_xor((int)b0, off));
+      b1 = min(b1, (unsigned)__shfl_xor((int)b1, off));
+      b2 = max(b2, (unsigned)__shfl_xor((int)b2, off));
+      b3 = max(b3, (unsigned)__shfl_xor((int)b3, off));
+    }
+    if (lane == 0) {
+      st.ct = ct;
+      st.bb[0] = b0;
+      st.bb[1] = b1;
+      st.bb[2] = b2;
+      st.bb[3] = b3;
+    }
+  } else if (PASS == 3) {
+    unsigned na = 0;
+    for (unsigned i = lane; i < sp.n_sb; i += kWave) na += part[(size_t)(sp.sb_off + i) * 6 + 5];
+    na = wave_sum_u32(na);
+    if (lane == 0) st.na = na;
+  }
+  if (lane != 0) return;
+  const float* s = sums + (size_t)j * kBigSums;
   const int sz = info[j].size;
   if (PASS == 1) {
     float m0 = 0.f, m1 = 0.f;

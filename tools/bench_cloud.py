@@ -57,7 +57,7 @@ def main():
               for name, ms, regions, by in ctx.profile() if regions]
     print(json.dumps({"kind": args.kind, "points": n, "status": st, "ms_per_cloud": dt * 1e3, "points_per_s": n / dt,
                       "n_raw": c.n_raw, "n_vox": c.n_vox, "n_fit": c.n_fit, "n_clusters": c.n_clusters,
-                      "n_planes": c.n_planes, "grid": list(c.grid), "stages": stages}))
+                      "n_planes": c.n_planes, "grid": list(c.grid), "xs": ctx.xs_stats(), "stages": stages}))
 
 
 def sharded(args):
