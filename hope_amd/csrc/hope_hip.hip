@@ -23,6 +23,7 @@
 #include "voxel_rank.hpp"
 #include "hull.hpp"
 #include "verify_big.hpp"
+#include "voxel_part.hpp"
 
 using namespace hope;
 
@@ -129,11 +130,11 @@ inline unsigned nblk(size_t n, int per = kBlock) { return (unsigned)((n + per - 
 // Optional per-stage timing with HIP events recorded on the ctx stream (bench.py's roofline
 // figures come from here; off by default).
 enum Stage {
-  ST_BBOX, ST_GRID, ST_VKEYS, ST_VSORT, ST_VRLE, ST_VRANK, ST_CENTROID, ST_COLKEYS, ST_COLSORT, ST_COLTABLE, ST_NORMALS,
+  ST_BBOX, ST_GRID, ST_VKEYS, ST_VSORT, ST_VRLE, ST_VRANK, ST_VPART, ST_VFINISH, ST_CENTROID, ST_COLKEYS, ST_COLSORT, ST_COLTABLE, ST_NORMALS,
   ST_FIT, ST_FITIDX, ST_KNN, ST_KNN_TODO, ST_LABELS, ST_SEGMENTS, ST_VERIFY, ST_COUNT
 };
 const char* const kStageNames[ST_COUNT] = {
-  "k_bbox", "k_frame_grid", "k_voxel_keys", "voxel_sort(rocprim)", "voxel_rle+scan(rocprim)", "k_voxel_rank", "k_centroids",
+  "k_bbox", "k_frame_grid", "k_voxel_keys", "voxel_sort(rocprim)", "voxel_rle+scan(rocprim)", "k_voxel_rank", "k_part_count+scatter", "k_part_finish", "k_centroids",
   "k_column_keys", "column_sort(rocprim)", "k_column_table+gather", "k_normals", "fit_gate+compact", "fit_column_index", "k_knn",
   "k_knn_todo",
   "labels(union+sweeps)", "segments(scan+sort)", "k_cluster_verify"};
@@ -207,6 +208,8 @@ struct hope_ctx {
   int knn_direct = 1;         // A6 and A8 read the column index straight from HBM through the caches, one thread per
   int normals_direct = 1;     // point (k_normals_direct, k_knn_direct); HOPE_DEBUG_NEIGHBOURS=tiles: the LDS tile kernels
   int tile_side = 0;          // neighbour tiles: 0 = chosen per call from the points per super tile; HOPE_DEBUG_TILE_SIDE=16|32 forces
+  int voxel_part = 1;         // one cloud: A5 by stable partition passes + one wave per 512-cell bucket (voxel_part.hpp;
+                              // HOPE_DEBUG_VOXEL_PART=0: keys, radix sort, run lengths, k_centroids_w)
   int voxel_rank = 1;         // depth batches: voxels ranked by an LDS bitmap per frame instead of sorting the group
                               // records (HOPE_DEBUG_VOXEL_RANK=0, or any knob that asks for a sort: the sorting path)
   uint32_t* d_grp_cnt = nullptr;  // depth path: groups per chunk, then its exclusive scan
@@ -606,6 +609,77 @@ int stage_voxel_rank(hope_ctx*, const CloudSrc&, size_t, size_t, int, const uint
   return HOPE_E_INVALID;  // (never called: clouds do not take the group path)
 }
 
+// A5 for one cloud by stable partition passes (voxel_part.hpp).
+template <class Src>
+int stage_voxel_part(hope_ctx* c, const Src& src, size_t N, int cell_bits, float4*& d_vox, int*& d_vox_frame)
+{
+  hipStream_t s = c->stream;
+  PrimAlloc pa{arena_alloc_cb, &c->arena};
+  const int high = cell_bits - kPartLow;
+  const int n_pass = (high + kPartMaxDigit - 1) / kPartMaxDigit;
+  const unsigned n_chunks = nblk(N, kPartChunk);
+  const unsigned n_buckets = (unsigned)(((c->h_glob->max_cells - 1ull) >> kPartLow) + 1ull);
+  char* buf[2];
+  uint32_t *counts, *offsets, *bstart, *vox_cnt, *vox_off;
+  ALLOC(buf[0], char, 16 * N);
+  ALLOC(buf[1], char, 16 * N);
+  ALLOC(counts, uint32_t, (size_t)kPartDigits * n_chunks + 1);
+  ALLOC(offsets, uint32_t, (size_t)kPartDigits * n_chunks + 1);
+  ALLOC(bstart, uint32_t, (size_t)n_buckets + 1);
+  ALLOC(vox_cnt, uint32_t, (size_t)n_buckets + 1);
+  ALLOC(vox_off, uint32_t, (size_t)n_buckets + 1);
+  auto cells_of = [&](int b) { return reinterpret_cast<uint32_t*>(buf[b]); };
+  auto xyz_of = [&](int b) { return reinterpret_cast<float*>(buf[b] + 4 * N); };
+  size_t pm = prof_mark(c);
+  int cur = 0, shift = kPartLow;
+  for (int p = 0; p < n_pass; ++p) {
+    const int bits = high / n_pass + (p < high % n_pass ? 1 : 0);
+    const size_t n_cnt = ((size_t)1 << bits) * n_chunks;
+    if (p == 0) {
+      hipLaunchKernelGGL((k_part_count<true, Src>), dim3(n_chunks), dim3(kBlock), 0, s, src, c->d_fi, c->inv_xy, c->inv_z,
+                         (const uint32_t*)nullptr, (unsigned)N, shift, bits, counts, n_chunks);
+      HIPCHK(exclusive_scan_u32(pa, counts, offsets, n_cnt, s));
+      hipLaunchKernelGGL((k_part_scatter<true, Src>), dim3(n_chunks), dim3(kBlock), 0, s, src, c->d_fi, c->inv_xy,
+                         c->inv_z, (const uint32_t*)nullptr, (const float*)nullptr, (unsigned)N, shift, bits, offsets,
+                         n_chunks, cells_of(0), xyz_of(0));
+      cur = 0;
+    } else {
+      hipLaunchKernelGGL((k_part_count<false, Src>), dim3(n_chunks), dim3(kBlock), 0, s, src, c->d_fi, c->inv_xy,
+                         c->inv_z, (const uint32_t*)cells_of(cur), (unsigned)N, shift, bits, counts, n_chunks);
+      HIPCHK(exclusive_scan_u32(pa, counts, offsets, n_cnt, s));
+      hipLaunchKernelGGL((k_part_scatter<false, Src>), dim3(n_chunks), dim3(kBlock), 0, s, src, c->d_fi, c->inv_xy,
+                         c->inv_z, (const uint32_t*)cells_of(cur), (const float*)xyz_of(cur), (unsigned)N, shift, bits,
+                         offsets, n_chunks, cells_of(cur ^ 1), xyz_of(cur ^ 1));
+      cur ^= 1;
+    }
+    shift += bits;
+  }
+  hipLaunchKernelGGL(k_part_bounds, dim3(nblk((size_t)n_buckets + 1)), dim3(kBlock), 0, s, (const uint32_t*)cells_of(cur),
+                     c->d_fi, n_buckets, bstart);
+  prof_close(c, ST_VPART, pm, (src_point_bytes(src) + 4.0) * (double)N);
+  pm = prof_mark(c);
+  float4* tmp = reinterpret_cast<float4*>(buf[cur ^ 1]);
+  HIPCHK(hipMemsetAsync(vox_cnt + n_buckets, 0, sizeof(uint32_t), s));
+  hipLaunchKernelGGL(k_part_finish, dim3(nblk(n_buckets, kBlock / kWave)), dim3(kBlock), 0, s,
+                     (const uint32_t*)cells_of(cur), (const float*)xyz_of(cur), bstart, n_buckets, tmp, vox_cnt);
+  HIPCHK(exclusive_scan_u32(pa, vox_cnt, vox_off, (size_t)n_buckets + 1, s));
+  hipLaunchKernelGGL(k_part_vox_total, dim3(1), dim3(1), 0, s, c->d_fi, vox_off, n_buckets, c->d_glob);
+  int st = sync_globals(c);
+  if (st != HOPE_OK) return st;
+  const unsigned n_vox = c->h_glob->n_vox_total;
+  c->n_vox_total = n_vox;
+  if (n_vox == 0) {
+    prof_close(c, ST_VFINISH, pm);
+    return HOPE_OK;
+  }
+  ALLOC(d_vox, float4, n_vox);
+  ALLOC(d_vox_frame, int, n_vox);
+  hipLaunchKernelGGL(k_part_compact, dim3(nblk(n_buckets, kBlock / kWave)), dim3(kBlock), 0, s, tmp, bstart, vox_off,
+                     n_buckets, d_vox, d_vox_frame);
+  prof_close(c, ST_VFINISH, pm, 16.0 * n_vox);
+  return HOPE_OK;
+}
+
 // A5.  Two ways to bring the points of a voxel together in ascending source index:
 //  * depth frames: sort one record per (64-pixel chunk, voxel) group (k_bbox_groups has already
 //    counted them, scan_groups placed them);
@@ -619,6 +693,9 @@ int stage_voxel(hope_ctx* c, const Src& src, size_t n_per_frame, int cell_bits, 
   hipStream_t s = c->stream;
   PrimAlloc pa{arena_alloc_cb, &c->arena};
   const bool groups = use_groups(c, src);
+  if (!groups && F == 1 && sizeof(VK) == 4 && c->voxel_part && !(c->h_glob->any_overflow & 1u) &&
+      cell_bits > kPartLow && N > 0)
+    return stage_voxel_part(c, src, N, cell_bits, d_vox, d_vox_frame);
   const size_t M = groups ? (size_t)c->h_glob->n_groups : N;  // records to sort
   if (M == 0) {
     c->n_vox_total = 0;
@@ -1443,6 +1520,8 @@ HOPE_API int hope_create(const hope_config* cfg, hope_ctx** out)
     c->normals_direct = std::strcmp(knob, "tiles-knn") == 0 ? 1 : 0;
     c->knn_direct = std::strcmp(knob, "tiles-normals") == 0 ? 1 : 0;
   }
+  knob = std::getenv("HOPE_DEBUG_VOXEL_PART");
+  c->voxel_part = (knob && knob[0] == '0') ? 0 : 1;
   knob = std::getenv("HOPE_DEBUG_VERIFY_BIG");
   if (knob) c->verify_big_from = std::atoi(knob);
   knob = std::getenv("HOPE_DEBUG_VOXEL_RANK");

@@ -185,6 +185,41 @@ def test_large_cluster_sums_by_integer_blocks(hip_lib, oracle_lib, monkeypatch, 
         assert_frame_equal(o, g, 0)
 
 
+def test_cloud_voxel_stage_by_partition_or_sort(hip_lib, oracle_lib, monkeypatch):
+    """A5 of a single cloud: stable partition passes + one wave per 512-cell bucket (voxel_part.hpp, the default)
+    and the previous stage (keys, radix sort, run lengths, k_centroids_w: HOPE_DEBUG_VOXEL_PART=0), on clouds of
+    one, two and three partition passes, with dropped points, and with one voxel that holds thousands of points."""
+    from hope_amd import synth
+    rng = np.random.default_rng(21)
+    small = synth.make_multilevel_cloud(300000, first_index=5, device="cpu").numpy() * np.float32(0.08)  # 2.4 m: one pass
+    mid = synth.make_multilevel_cloud(500000, first_index=99, device="cpu").numpy()                      # 30 m: two passes
+    wide = np.concatenate([mid * np.float32(3.0), mid[:50000] * np.float32(8.0)])                        # 240 m: three
+    dense = np.concatenate([mid[:200000], np.float32([3.0, 3.0, 1.0]) + rng.uniform(0, 0.019, (6000, 3)).astype(np.float32)])
+    dense = dense[rng.permutation(len(dense))]
+    holes = mid.copy()
+    holes[::7, 2] = np.nan
+    o = HopeContext(oracle_lib)
+    for knob in (None, "0"):
+        if knob is not None:
+            monkeypatch.setenv("HOPE_DEBUG_VOXEL_PART", knob)
+        g = HopeContext(hip_lib)
+        monkeypatch.delenv("HOPE_DEBUG_VOXEL_PART", raising=False)
+        for xyz in (small, mid, wide, dense, holes):
+            for c in (g, o):
+                assert c.segment_cloud(xyz) == 0
+            assert_frame_equal(o, g, 0)
+        t = np.array([0.1, -0.2, 0.3], np.float32)
+        q = np.array([0.02, -0.01, 0.38, 0.92], np.float32)
+        posed = mid * np.float32(0.25) + np.array([0, 0, 0.2], np.float32)
+        for c in (g, o):
+            c.set_pose(t, q)
+            c.segment_cloud(posed, apply_filter_transform=True)
+        assert o.counts(0).n_raw < posed.shape[0]
+        assert_frame_equal(o, g, 0, check_transformed=True)
+        for c in (g, o):
+            c.set_pose(np.zeros(3, np.float32), np.array([0, 0, 0, 1], np.float32))
+
+
 def test_rt_mode_and_height_window(hip_lib, oracle_lib):
     z = np.load(os.path.join(GOLDEN, "synth_frames_0_2.npz"))
     g, o = both(hip_lib, oracle_lib, mode=HOPE_MODE_RT, min_height=0.6, max_height=0.9)
