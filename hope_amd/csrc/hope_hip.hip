@@ -614,22 +614,21 @@ template <class Src>
 int stage_voxel_part(hope_ctx* c, const Src& src, size_t N, int cell_bits, float4*& d_vox, int*& d_vox_frame)
 {
   hipStream_t s = c->stream;
-  PrimAlloc pa{arena_alloc_cb, &c->arena};
   const int high = cell_bits - kPartLow;
   const int n_pass = (high + kPartMaxDigit - 1) / kPartMaxDigit;
   const unsigned n_chunks = nblk(N, kPartChunk);
   const unsigned n_buckets = (unsigned)(((c->h_glob->max_cells - 1ull) >> kPartLow) + 1ull);
-  char* buf[2];
-  uint32_t *counts, *offsets, *bstart, *vox_cnt, *vox_off;
-  ALLOC(buf[0], char, 16 * N);
-  ALLOC(buf[1], char, 16 * N);
-  ALLOC(counts, uint32_t, (size_t)kPartDigits * n_chunks + 1);
-  ALLOC(offsets, uint32_t, (size_t)kPartDigits * n_chunks + 1);
-  ALLOC(bstart, uint32_t, (size_t)n_buckets + 1);
-  ALLOC(vox_cnt, uint32_t, (size_t)n_buckets + 1);
-  ALLOC(vox_off, uint32_t, (size_t)n_buckets + 1);
-  auto cells_of = [&](int b) { return reinterpret_cast<uint32_t*>(buf[b]); };
-  auto xyz_of = [&](int b) { return reinterpret_cast<float*>(buf[b] + 4 * N); };
+  float4* buf[2];
+  uint32_t *counts, *sums, *bstart, *vox_cnt, *big, *big_n;
+  const size_t n_cnt_max = (size_t)kPartDigits * n_chunks;
+  ALLOC(buf[0], float4, N);
+  ALLOC(buf[1], float4, N);
+  ALLOC(counts, uint32_t, n_cnt_max + 4);
+  ALLOC(sums, uint32_t, scan_sums_words(std::max(n_cnt_max, (size_t)n_buckets + 1)));
+  ALLOC(bstart, uint32_t, (size_t)n_buckets + 4);
+  ALLOC(vox_cnt, uint32_t, (size_t)n_buckets + 4);
+  ALLOC(big, uint32_t, (size_t)n_buckets + 4);
+  ALLOC(big_n, uint32_t, 4);
   size_t pm = prof_mark(c);
   int cur = 0, shift = kPartLow;
   for (int p = 0; p < n_pass; ++p) {
@@ -637,33 +636,36 @@ int stage_voxel_part(hope_ctx* c, const Src& src, size_t N, int cell_bits, float
     const size_t n_cnt = ((size_t)1 << bits) * n_chunks;
     if (p == 0) {
       hipLaunchKernelGGL((k_part_count<true, Src>), dim3(n_chunks), dim3(kBlock), 0, s, src, c->d_fi, c->inv_xy, c->inv_z,
-                         (const uint32_t*)nullptr, (unsigned)N, shift, bits, counts, n_chunks);
-      HIPCHK(exclusive_scan_u32(pa, counts, offsets, n_cnt, s));
-      hipLaunchKernelGGL((k_part_scatter<true, Src>), dim3(n_chunks), dim3(kBlock), 0, s, src, c->d_fi, c->inv_xy,
-                         c->inv_z, (const uint32_t*)nullptr, (const float*)nullptr, (unsigned)N, shift, bits, offsets,
-                         n_chunks, cells_of(0), xyz_of(0));
+                         (const float4*)nullptr, (unsigned)N, shift, bits, counts, n_chunks);
+      scan_exclusive_u32(counts, counts, n_cnt, sums, s);
+      hipLaunchKernelGGL((k_part_scatter<true, Src>), dim3(n_chunks), dim3(kPartThreads), 0, s, src, c->d_fi, c->inv_xy,
+                         c->inv_z, (const float4*)nullptr, (unsigned)N, shift, bits, (const uint32_t*)counts, n_chunks,
+                         buf[0]);
       cur = 0;
     } else {
       hipLaunchKernelGGL((k_part_count<false, Src>), dim3(n_chunks), dim3(kBlock), 0, s, src, c->d_fi, c->inv_xy,
-                         c->inv_z, (const uint32_t*)cells_of(cur), (unsigned)N, shift, bits, counts, n_chunks);
-      HIPCHK(exclusive_scan_u32(pa, counts, offsets, n_cnt, s));
-      hipLaunchKernelGGL((k_part_scatter<false, Src>), dim3(n_chunks), dim3(kBlock), 0, s, src, c->d_fi, c->inv_xy,
-                         c->inv_z, (const uint32_t*)cells_of(cur), (const float*)xyz_of(cur), (unsigned)N, shift, bits,
-                         offsets, n_chunks, cells_of(cur ^ 1), xyz_of(cur ^ 1));
+                         c->inv_z, (const float4*)buf[cur], (unsigned)N, shift, bits, counts, n_chunks);
+      scan_exclusive_u32(counts, counts, n_cnt, sums, s);
+      hipLaunchKernelGGL((k_part_scatter<false, Src>), dim3(n_chunks), dim3(kPartThreads), 0, s, src, c->d_fi, c->inv_xy,
+                         c->inv_z, (const float4*)buf[cur], (unsigned)N, shift, bits, (const uint32_t*)counts, n_chunks,
+                         buf[cur ^ 1]);
       cur ^= 1;
     }
     shift += bits;
   }
-  hipLaunchKernelGGL(k_part_bounds, dim3(nblk((size_t)n_buckets + 1)), dim3(kBlock), 0, s, (const uint32_t*)cells_of(cur),
+  hipLaunchKernelGGL(k_part_bounds, dim3(nblk((size_t)n_buckets + 1)), dim3(kBlock), 0, s, (const float4*)buf[cur],
                      c->d_fi, n_buckets, bstart);
   prof_close(c, ST_VPART, pm, (src_point_bytes(src) + 4.0) * (double)N);
   pm = prof_mark(c);
-  float4* tmp = reinterpret_cast<float4*>(buf[cur ^ 1]);
+  float4* tmp = buf[cur ^ 1];
   HIPCHK(hipMemsetAsync(vox_cnt + n_buckets, 0, sizeof(uint32_t), s));
-  hipLaunchKernelGGL(k_part_finish, dim3(nblk(n_buckets, kBlock / kWave)), dim3(kBlock), 0, s,
-                     (const uint32_t*)cells_of(cur), (const float*)xyz_of(cur), bstart, n_buckets, tmp, vox_cnt);
-  HIPCHK(exclusive_scan_u32(pa, vox_cnt, vox_off, (size_t)n_buckets + 1, s));
-  hipLaunchKernelGGL(k_part_vox_total, dim3(1), dim3(1), 0, s, c->d_fi, vox_off, n_buckets, c->d_glob);
+  HIPCHK(hipMemsetAsync(big_n, 0, 4 * sizeof(uint32_t), s));
+  hipLaunchKernelGGL(k_part_finish_small, dim3(nblk(n_buckets, kFinWaves)), dim3(kFinThreads), 0, s,
+                     (const float4*)buf[cur], (const uint32_t*)bstart, n_buckets, tmp, vox_cnt, big, big_n);
+  hipLaunchKernelGGL(k_part_finish_big, dim3(kFinGrid), dim3(kFinThreads), 0, s, (const float4*)buf[cur],
+                     (const uint32_t*)bstart, (const uint32_t*)big, big_n, tmp, vox_cnt);
+  scan_exclusive_u32(vox_cnt, vox_cnt, (size_t)n_buckets + 1, sums, s);  // now: the buckets' first voxels
+  hipLaunchKernelGGL(k_part_vox_total, dim3(1), dim3(1), 0, s, c->d_fi, (const uint32_t*)vox_cnt, n_buckets, c->d_glob);
   int st = sync_globals(c);
   if (st != HOPE_OK) return st;
   const unsigned n_vox = c->h_glob->n_vox_total;
@@ -674,8 +676,8 @@ int stage_voxel_part(hope_ctx* c, const Src& src, size_t N, int cell_bits, float
   }
   ALLOC(d_vox, float4, n_vox);
   ALLOC(d_vox_frame, int, n_vox);
-  hipLaunchKernelGGL(k_part_compact, dim3(nblk(n_buckets, kBlock / kWave)), dim3(kBlock), 0, s, tmp, bstart, vox_off,
-                     n_buckets, d_vox, d_vox_frame);
+  hipLaunchKernelGGL(k_part_compact, dim3(nblk(n_buckets, kBlock / kWave)), dim3(kBlock), 0, s, (const float4*)tmp,
+                     (const uint32_t*)bstart, (const uint32_t*)vox_cnt, n_buckets, d_vox, d_vox_frame);
   prof_close(c, ST_VFINISH, pm, 16.0 * n_vox);
   return HOPE_OK;
 }

@@ -5,20 +5,23 @@
 // centroid is a sequential float sum -- the points of a voxel in ascending input index.  The sort-based stage
 // (k_voxel_keys, radix sort of 10^8 pairs, run-length encode, k_centroids_w) moves 8-byte pairs four times
 // and then fetches every point again through a 64-byte sector for its 12 bytes: 7.2 ms for 10^8 points.
-// Here the POINT travels, and only as far as it has to:
+// Here the POINT travels, as one 16-byte record (x, y, z, cell), and only as far as it has to:
 //   * the cell index is cut into  [ high digits | low 9 bits ].  One stable partition pass per high digit
-//     (least significant first: k_part_count, a scan of the chunk x digit counts, k_part_scatter) moves
-//     (cell, x, y, z) records so that afterwards every BUCKET -- the 512 cells that share their high digits
-//     -- is one contiguous range, its records still in input order.  Two passes of 9 bits for the 2^27 cells
-//     of the 10^8-point scene.  A pass ranks the records of a 2048-record tile by wave-wide ballot matching
-//     (stable by construction), reorders the tile in LDS and writes runs, so stores stay coalesced.
-//   * k_part_finish gives each bucket to ONE wave, which walks its records in order and adds each to the
-//     accumulator of its cell in LDS.  Records of a batch that share a cell are added in lane order (the
-//     lowest pending lane of a cell wins an LDS min and goes first), so every cell's sum is the reference's
-//     chain, and lanes with different cells go at the same time.  Occupied cells leave in ascending order.
+//     (least significant first: k_part_count, a scan of the digit x chunk counts, k_part_scatter) moves the
+//     records so that afterwards every BUCKET -- the 512 cells that share their high digits -- is one
+//     contiguous range, its records still in input order.  Two passes of 9 bits for the 2^27 cells of the
+//     10^8-point scene.  A pass ranks the records of a 4096-record tile by wave-wide ballot matching (stable
+//     by construction), reorders the tile in LDS and writes runs of whole records.
+//   * k_part_finish turns a bucket into its voxels.  A bucket of up to 64 records (clutter) is one wave's
+//     work: lanes with the same cell are found by ballots and the first of them adds the group's points in
+//     lane order.  Any other bucket is a workgroup's: tiles of 2048 records are ranked by cell the same way,
+//     reordered in LDS, and one thread per cell adds its run to the cell's running sums in registers -- a
+//     shelf row of 10^5 records in 30 cells costs 30 chains in parallel, not one wave's walk over all of them.
+//     Every cell's sum is the reference's chain (ascending input index); occupied cells leave in ascending order.
 // No step needs the input index itself: stability carries the order.
 #pragma once
 #include "kernels.hpp"
+#include "scan.hpp"
 
 namespace hope {
 
@@ -26,10 +29,16 @@ constexpr int kPartLow = 9;                        // low cell bits: cells of a 
 constexpr int kPartCells = 1 << kPartLow;          // 512
 constexpr int kPartMaxDigit = 9;                   // bits per partition pass
 constexpr int kPartDigits = 1 << kPartMaxDigit;    // 512
+constexpr int kPartThreads = 512;                  // workgroup of a scatter pass (one digit per thread)
 constexpr int kPartIPT = 8;                        // records per thread and tile
-constexpr int kPartTile = kBlock * kPartIPT;       // 2048
-constexpr int kPartChunk = 8 * kPartTile;          // 16384 records per workgroup
-constexpr unsigned kPartNone = 0xffffffffu;
+constexpr int kPartTile = kPartThreads * kPartIPT; // 4096
+constexpr int kPartChunk = 4 * kPartTile;          // 16384 records per workgroup
+constexpr int kFinThreads = 256;                   // workgroup of k_part_finish
+constexpr int kFinWaves = kFinThreads / kWave;
+constexpr int kFinTile = kFinThreads * 8;          // 2048 records
+constexpr int kFinGrid = 1024;                     // workgroups of k_part_finish_big (4 per CU)
+static_assert(kPartThreads == kPartDigits, "k_part_scatter scans one digit per thread");
+static_assert(kFinThreads * 2 == kPartCells, "k_part_finish keeps two cells per thread");
 
 // cell index of input point i (A2/A3 applied), false if the point is dropped
 template <class Src>
@@ -45,11 +54,23 @@ __device__ __forceinline__ bool part_cell(const Src& src, const FrameInfo* fi, f
   return true;
 }
 
+// lanes of the wave whose `ok` is set and whose low `bits` bits of d equal this lane's
+__device__ __forceinline__ unsigned long long match_lanes(unsigned d, int bits, bool ok)
+{
+  unsigned long long same = __ballot(ok);
+  for (int b = 0; b < bits; ++b) {
+    const bool bit = (d >> b) & 1u;
+    const unsigned long long v = __ballot(bit);
+    same &= bit ? v : ~v;
+  }
+  return same;
+}
+
 // ---- counts[digit][chunk] of one pass ------------------------------------------------------------
-// FROM_SRC: the first pass reads the input; later passes read the cell array of the previous pass
+// FROM_SRC: the first pass reads the input; later passes read the records of the previous pass
 template <bool FROM_SRC, class Src>
 __global__ void __launch_bounds__(kBlock)
-k_part_count(Src src, const FrameInfo* fi, float inv_xy, float inv_z, const uint32_t* cell_in, unsigned n, int shift,
+k_part_count(Src src, const FrameInfo* fi, float inv_xy, float inv_z, const float4* rec_in, unsigned n, int shift,
              int bits, uint32_t* counts, unsigned n_chunks)
 {
   __shared__ unsigned s_hist[kPartDigits];
@@ -67,7 +88,7 @@ k_part_count(Src src, const FrameInfo* fi, float inv_xy, float inv_z, const uint
       float x, y, z;
       ok = part_cell(src, fi, inv_xy, inv_z, i, x, y, z, cell);
     } else {
-      cell = cell_in[i];
+      cell = __float_as_uint(rec_in[i].w);
       ok = true;
     }
     if (ok) atomicAdd(&s_hist[(cell >> shift) & mask], 1u);
@@ -81,135 +102,106 @@ k_part_count(Src src, const FrameInfo* fi, float inv_xy, float inv_z, const uint
 // Record order inside a tile: wave w owns records [512 w, 512 w + 512) of the tile, item k of lane l is
 // record 512 w + 64 k + l (coalesced loads); ranks follow that order.
 template <bool FROM_SRC, class Src>
-__global__ void __launch_bounds__(kBlock)
-k_part_scatter(Src src, const FrameInfo* fi, float inv_xy, float inv_z, const uint32_t* cell_in, const float* xyz_in,
-               unsigned n, int shift, int bits, const uint32_t* offsets, unsigned n_chunks, uint32_t* cell_out,
-               float* xyz_out)
+__global__ void __launch_bounds__(kPartThreads)
+k_part_scatter(Src src, const FrameInfo* fi, float inv_xy, float inv_z, const float4* rec_in, unsigned n, int shift,
+               int bits, const uint32_t* offsets, unsigned n_chunks, float4* rec_out)
 {
-  constexpr int kWaves = kBlock / kWave;
-  __shared__ unsigned s_cnt[kWaves][kPartDigits];  // records of (wave, digit) so far; then the waves' prefix
-  __shared__ unsigned s_tot[kPartDigits];          // records of a digit in this tile
-  __shared__ unsigned s_dstart[kPartDigits];       // where the digit starts in the reordered tile
-  __shared__ unsigned s_base[kPartDigits];         // where the chunk's next record of a digit goes
+  constexpr int kWaves = kPartThreads / kWave;
+  __shared__ unsigned short s_cnt[kWaves][kPartDigits];  // records of (wave, digit) so far; then the waves' prefix
+  __shared__ unsigned short s_dstart[kPartDigits];       // where the digit starts in the reordered tile
+  __shared__ unsigned s_base[kPartDigits];               // where the chunk's next record of a digit goes
   __shared__ unsigned s_scan[kWaves];
-  __shared__ unsigned s_cell[kPartTile];
-  __shared__ float s_xyz[3 * kPartTile];
+  __shared__ float4 s_rec[kPartTile];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid / kWave;
   const unsigned chunk = blockIdx.x;
   const int nd = 1 << bits;
   const unsigned dmask = (unsigned)nd - 1u;
-  for (int d = tid; d < kPartDigits; d += kBlock) s_base[d] = d < nd ? offsets[(size_t)d * n_chunks + chunk] : 0u;
+  s_base[tid] = tid < nd ? offsets[(size_t)tid * n_chunks + chunk] : 0u;
   if (!FROM_SRC) n = (unsigned)fi[0].n_raw;
   const unsigned c_lo = min(n, chunk * (unsigned)kPartChunk);
   const unsigned c_hi = min(n, c_lo + (unsigned)kPartChunk);
   const unsigned long long lt = (1ull << lane) - 1ull;
+  unsigned my_tot = 0u;  // records of digit `tid` in the previous tile
   for (unsigned t0 = c_lo; t0 < c_hi; t0 += kPartTile) {
-    for (int i = tid; i < kWaves * kPartDigits; i += kBlock) (&s_cnt[0][0])[i] = 0u;
-    __syncthreads();
-    unsigned cell[kPartIPT], rank[kPartIPT];
-    float px[kPartIPT], py[kPartIPT], pz[kPartIPT];
+    {
+      unsigned* z = reinterpret_cast<unsigned*>(&s_cnt[0][0]);
+      for (int i = tid; i < kWaves * kPartDigits / 2; i += kPartThreads) z[i] = 0u;
+    }
+    __syncthreads();  // (every reader of the previous tile's s_rec, s_dstart and s_base is done)
+    s_base[tid] += my_tot;  // (read again only after the barriers below)
+    float4 r[kPartIPT];
+    unsigned short rank[kPartIPT];
     bool ok[kPartIPT];
     // loads first (all in flight together), ranking afterwards
 #pragma unroll
     for (int k = 0; k < kPartIPT; ++k) {
       const unsigned i = t0 + (unsigned)(w * (kWave * kPartIPT) + k * kWave + lane);
       ok[k] = i < c_hi;
-      cell[k] = 0u;
-      px[k] = py[k] = pz[k] = 0.f;
+      r[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ok[k]) {
         if (FROM_SRC) {
-          ok[k] = part_cell(src, fi, inv_xy, inv_z, i, px[k], py[k], pz[k], cell[k]);
+          unsigned cell = 0u;
+          ok[k] = part_cell(src, fi, inv_xy, inv_z, i, r[k].x, r[k].y, r[k].z, cell);
+          r[k].w = __uint_as_float(cell);
         } else {
-          cell[k] = cell_in[i];
-          px[k] = xyz_in[3 * (size_t)i];
-          py[k] = xyz_in[3 * (size_t)i + 1];
-          pz[k] = xyz_in[3 * (size_t)i + 2];
+          r[k] = rec_in[i];
         }
       }
     }
 #pragma unroll
     for (int k = 0; k < kPartIPT; ++k) {
-      const unsigned d = (cell[k] >> shift) & dmask;
-      // lanes of this batch with the same digit
-      unsigned long long same = __ballot(ok[k]);
-      for (int b = 0; b < bits; ++b) {
-        const bool bit = (d >> b) & 1u;
-        const unsigned long long v = __ballot(bit);
-        same &= bit ? v : ~v;
-      }
+      const unsigned d = (__float_as_uint(r[k].w) >> shift) & dmask;
+      const unsigned long long same = match_lanes(d, bits, ok[k]);
       const unsigned before = s_cnt[w][d];  // (the wave's batches run in order: only this wave touches its row)
-      rank[k] = before + (unsigned)__popcll(same & lt);
-      if (ok[k] && (same & lt) == 0ull) s_cnt[w][d] = before + (unsigned)__popcll(same);
+      rank[k] = (unsigned short)(before + (unsigned)__popcll(same & lt));
+      __builtin_amdgcn_wave_barrier();
+      if (ok[k] && (same & lt) == 0ull) s_cnt[w][d] = (unsigned short)(before + (unsigned)__popcll(same));
+      __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    // per digit: prefix over the waves, total; then the digits' starts in the reordered tile
-    unsigned my_tot[kPartDigits / kBlock];
+    // digit `tid`: prefix over the waves, total; then the digits' starts in the reordered tile
+    unsigned run = 0u;
 #pragma unroll
-    for (int j = 0; j < kPartDigits / kBlock; ++j) {
-      const int d = tid * (kPartDigits / kBlock) + j;  // consecutive digits per thread: the scan below is in digit order
-      unsigned run = 0u;
-#pragma unroll
-      for (int ww = 0; ww < kWaves; ++ww) {
-        const unsigned c = s_cnt[ww][d];
-        s_cnt[ww][d] = run;
-        run += c;
-      }
-      s_tot[d] = run;
-      my_tot[j] = run;
+    for (int ww = 0; ww < kWaves; ++ww) {
+      const unsigned c = s_cnt[ww][tid];
+      s_cnt[ww][tid] = (unsigned short)run;
+      run += c;
     }
-    unsigned mine = 0u;
-#pragma unroll
-    for (int j = 0; j < kPartDigits / kBlock; ++j) mine += my_tot[j];
-    unsigned inc = mine;
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-      const unsigned t = (unsigned)__shfl_up((int)inc, o);
-      if (lane >= o) inc += t;
-    }
+    my_tot = run;
+    const unsigned inc = wave_incl_scan(run, lane);
     if (lane == kWave - 1) s_scan[w] = inc;
     __syncthreads();
-    unsigned pre = inc - mine;
-    for (int ww = 0; ww < w; ++ww) pre += s_scan[ww];
-    unsigned tile_n = 0u;
-    for (int ww = 0; ww < kWaves; ++ww) tile_n += s_scan[ww];
+    unsigned pre = inc - run, tile_n = 0u;
 #pragma unroll
-    for (int j = 0; j < kPartDigits / kBlock; ++j) {
-      s_dstart[tid * (kPartDigits / kBlock) + j] = pre;
-      pre += my_tot[j];
+    for (int ww = 0; ww < kWaves; ++ww) {
+      const unsigned t = s_scan[ww];
+      if (ww < w) pre += t;
+      tile_n += t;
     }
+    s_dstart[tid] = (unsigned short)pre;
     __syncthreads();
     // reorder the tile in LDS
 #pragma unroll
     for (int k = 0; k < kPartIPT; ++k) {
       if (!ok[k]) continue;
-      const unsigned d = (cell[k] >> shift) & dmask;
-      const unsigned p = s_dstart[d] + s_cnt[w][d] + rank[k];
-      s_cell[p] = cell[k];
-      s_xyz[3 * p] = px[k];
-      s_xyz[3 * p + 1] = py[k];
-      s_xyz[3 * p + 2] = pz[k];
+      const unsigned d = (__float_as_uint(r[k].w) >> shift) & dmask;
+      s_rec[(unsigned)s_dstart[d] + (unsigned)s_cnt[w][d] + (unsigned)rank[k]] = r[k];
     }
     __syncthreads();
     // write the runs out
-    for (unsigned p = tid; p < tile_n; p += kBlock) {
-      const unsigned cl = s_cell[p];
-      const unsigned d = (cl >> shift) & dmask;
-      const size_t g = (size_t)s_base[d] + (p - s_dstart[d]);
-      cell_out[g] = cl;
-      xyz_out[3 * g] = s_xyz[3 * p];
-      xyz_out[3 * g + 1] = s_xyz[3 * p + 1];
-      xyz_out[3 * g + 2] = s_xyz[3 * p + 2];
+    for (unsigned p = tid; p < tile_n; p += kPartThreads) {
+      const float4 q = s_rec[p];
+      const unsigned d = (__float_as_uint(q.w) >> shift) & dmask;
+      rec_out[(size_t)s_base[d] + (p - (unsigned)s_dstart[d])] = q;
     }
-    __syncthreads();
-    for (int d = tid; d < nd; d += kBlock) s_base[d] += s_tot[d];
-    // (the next tile's first barrier orders this against its readers)
+    // (the next tile's first barrier orders its LDS writes against these reads)
   }
 }
 
 // ---- bucket ranges of the partitioned records -----------------------------------------------------
 // bstart[h] = first record whose (cell >> kPartLow) >= h, for h = 0 .. n_buckets (a binary search per bucket)
 __global__ void __launch_bounds__(kBlock)
-k_part_bounds(const uint32_t* cell, const FrameInfo* fi, unsigned n_buckets, uint32_t* bstart)
+k_part_bounds(const float4* rec, const FrameInfo* fi, unsigned n_buckets, uint32_t* bstart)
 {
   const unsigned m = (unsigned)fi[0].n_raw;  // records that survived A2 (counted by k_bbox)
   const unsigned h = blockIdx.x * kBlock + threadIdx.x;
@@ -217,101 +209,230 @@ k_part_bounds(const uint32_t* cell, const FrameInfo* fi, unsigned n_buckets, uin
   unsigned lo = 0u, hi = m;
   while (lo < hi) {
     const unsigned mid = lo + ((hi - lo) >> 1);
-    if ((cell[mid] >> kPartLow) < h) lo = mid + 1u; else hi = mid;
+    if ((__float_as_uint(rec[mid].w) >> kPartLow) < h) lo = mid + 1u; else hi = mid;
   }
   bstart[h] = lo;
 }
 
-// ---- centroids: one wave per bucket -----------------------------------------------------------------
+// ---- centroids ------------------------------------------------------------------------------------
 // out: the bucket's voxels in ascending cell order at out[bstart[b] ...] (a bucket has at most as many voxels as
 // records), vox_cnt[b] their number.
-__global__ void __launch_bounds__(kBlock)
-k_part_finish(const uint32_t* cell, const float* xyz, const uint32_t* bstart, unsigned n_buckets, float4* out,
-              uint32_t* vox_cnt)
+//
+// k_part_finish_small: one wave per bucket.  Empty buckets and buckets of up to 64 records are finished here;
+// the others are appended to `big` (big_n[0] counts them; any order).
+__global__ void __launch_bounds__(kFinThreads)
+k_part_finish_small(const float4* rec, const uint32_t* bstart, unsigned n_buckets, float4* out, uint32_t* vox_cnt,
+                    uint32_t* big, uint32_t* big_n)
 {
-  constexpr int kWaves = kBlock / kWave;
-  constexpr int kPer = kPartCells / kWave;  // cells per lane at the end
-  __shared__ float s_x[kWaves][kPartCells], s_y[kWaves][kPartCells], s_z[kWaves][kPartCells];
-  __shared__ unsigned s_n[kWaves][kPartCells];
-  __shared__ unsigned s_slot[kWaves][kPartCells];
+  __shared__ float4 s_rec[kFinWaves][kWave];
+  __shared__ unsigned s_bits[kFinWaves][kPartCells / 32];
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
-  const unsigned b = blockIdx.x * kWaves + w;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const unsigned cmask = (unsigned)kPartCells - 1u;
+  const unsigned b = blockIdx.x * kFinWaves + w;
   if (b >= n_buckets) return;
-  const unsigned r_lo = bstart[b], r_hi = bstart[b + 1];
-  if (r_lo == r_hi) {
+  const unsigned lo = bstart[b], hi = bstart[b + 1];
+  if (hi == lo) {
     if (lane == 0) vox_cnt[b] = 0u;
     return;
   }
-  float* ax = s_x[w];
-  float* ay = s_y[w];
-  float* az = s_z[w];
-  unsigned* an = s_n[w];
-  volatile unsigned* slot = s_slot[w];
-  for (int c = lane; c < kPartCells; c += kWave) {
-    ax[c] = 0.f;
-    ay[c] = 0.f;
-    az[c] = 0.f;
-    an[c] = 0u;
-    slot[c] = kPartNone;
+  if (hi - lo > (unsigned)kWave) {
+    if (lane == 0) big[atomicAdd(big_n, 1u)] = b;
+    return;
   }
+  const bool ok = lo + (unsigned)lane < hi;
+  const float4 r = ok ? rec[lo + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const unsigned key = __float_as_uint(r.w) & cmask;
+  const unsigned long long same = match_lanes(key, kPartLow, ok);
+  const bool first = ok && (same & lt) == 0ull;
+  s_rec[w][lane] = r;
+  if (lane < kPartCells / 32) s_bits[w][lane] = 0u;
   __builtin_amdgcn_wave_barrier();
-  for (unsigned r0 = r_lo; r0 < r_hi; r0 += 4 * kWave) {
-    // four batches in flight
-    unsigned cl[4];
-    float px[4], py[4], pz[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const unsigned i = r0 + (unsigned)(q * kWave + lane);
-      const unsigned ii = min(i, r_hi - 1u);
-      cl[q] = i < r_hi ? (cell[ii] & (unsigned)(kPartCells - 1)) : kPartNone;
-      px[q] = xyz[3 * (size_t)ii];
-      py[q] = xyz[3 * (size_t)ii + 1];
-      pz[q] = xyz[3 * (size_t)ii + 2];
+  if (first) atomicOr(&s_bits[w][key >> 5], 1u << (key & 31u));
+  __builtin_amdgcn_wave_barrier();
+  if (first) {
+    // the group's points in lane order = ascending input index
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    unsigned cnt = 0u;
+    unsigned long long m = same;
+    while (m) {
+      const int j = __ffsll((long long)m) - 1;
+      m &= m - 1ull;
+      const float4 q = s_rec[w][j];
+      ax = ax + q.x;
+      ay = ay + q.y;
+      az = az + q.z;
+      ++cnt;
     }
+    unsigned pos = 0u;
+    const unsigned kw = key >> 5;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      bool pending = cl[q] != kPartNone;
-      const unsigned c = pending ? cl[q] : 0u;
-      while (__any(pending)) {
-        // the lowest pending lane of every cell goes now: ascending lane = ascending input index
-        if (pending) atomicMin(const_cast<unsigned*>(&slot[c]), (unsigned)lane);
+    for (int i = 0; i < kPartCells / 32; ++i) {
+      const unsigned bw = s_bits[w][i];
+      if ((unsigned)i < kw) pos += (unsigned)__popc(bw);
+      if ((unsigned)i == kw) pos += (unsigned)__popc(bw & ((1u << (key & 31u)) - 1u));
+    }
+    const float fn = (float)cnt;
+    out[lo + pos] = make_float4(ax / fn, ay / fn, az / fn, 0.f);
+  }
+  const unsigned long long firsts = __ballot(first);
+  if (lane == 0) vox_cnt[b] = (unsigned)__popcll(firsts);
+}
+
+// k_part_finish_big: the listed buckets, each by a whole workgroup; the workgroups of a fixed-size grid take the
+// next bucket of the list until it is used up (big_n[0] = length, big_n[1] = next entry, zero at launch).
+__global__ void __launch_bounds__(kFinThreads)
+k_part_finish_big(const float4* rec, const uint32_t* bstart, const uint32_t* big, uint32_t* big_n, float4* out,
+                  uint32_t* vox_cnt)
+{
+  __shared__ float4 s_rec[kFinTile];
+  __shared__ unsigned short s_cnt[kFinWaves][kPartCells];
+  __shared__ unsigned short s_cstart[kPartCells];
+  __shared__ unsigned short s_ctot[kPartCells];
+  __shared__ unsigned s_scan[kFinWaves];
+  __shared__ unsigned s_next;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid / kWave;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const unsigned cmask = (unsigned)kPartCells - 1u;
+  const unsigned n_big = big_n[0];
+  for (;;) {
+    __syncthreads();  // (s_next, s_scan: the readers of the previous round are done)
+    if (tid == 0) s_next = atomicAdd(&big_n[1], 1u);
+    __syncthreads();
+    const unsigned at = s_next;
+    if (at >= n_big) break;  // (the same for every thread; every workgroup gets here: the list is finite)
+    const unsigned b = big[at];
+    const unsigned lo = bstart[b], hi = bstart[b + 1];
+    // this thread's cells: tid and tid + 256 (a shelf row is a run of adjacent cells: one chain per lane)
+    float ax[2] = {0.f, 0.f}, ay[2] = {0.f, 0.f}, az[2] = {0.f, 0.f};
+    unsigned an[2] = {0u, 0u};
+    float4 r[8];
+    bool ok[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const unsigned i = lo + (unsigned)(w * (kWave * 8) + k * kWave + lane);
+      ok[k] = i < hi;
+      r[k] = ok[k] ? rec[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (unsigned t0 = lo; t0 < hi; t0 += kFinTile) {
+      {
+        unsigned* z = reinterpret_cast<unsigned*>(&s_cnt[0][0]);
+        for (int i = tid; i < kFinWaves * kPartCells / 2; i += kFinThreads) z[i] = 0u;
+      }
+      __syncthreads();  // (also: every reader of the previous tile's s_rec, s_cstart and s_ctot is done)
+      unsigned short rank[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        rank[k] = 0;
+        if (__ballot(ok[k]) == 0ull) continue;
+        const unsigned d = __float_as_uint(r[k].w) & cmask;
+        const unsigned long long same = match_lanes(d, kPartLow, ok[k]);
+        const unsigned before = s_cnt[w][d];
+        rank[k] = (unsigned short)(before + (unsigned)__popcll(same & lt));
         __builtin_amdgcn_wave_barrier();
-        const bool win = pending && slot[c] == (unsigned)lane;
-        __builtin_amdgcn_wave_barrier();
-        if (win) {
-          ax[c] = ax[c] + px[q];
-          ay[c] = ay[c] + py[q];
-          az[c] = az[c] + pz[q];
-          an[c] = an[c] + 1u;
-          slot[c] = kPartNone;
-          pending = false;
-        }
+        if (ok[k] && (same & lt) == 0ull) s_cnt[w][d] = (unsigned short)(before + (unsigned)__popcll(same));
         __builtin_amdgcn_wave_barrier();
       }
+      __syncthreads();
+      // cells 2 tid and 2 tid + 1: prefix over the waves, then over the cells
+      unsigned tot[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c = 2 * tid + j;
+        unsigned run = 0u;
+#pragma unroll
+        for (int ww = 0; ww < kFinWaves; ++ww) {
+          const unsigned v = s_cnt[ww][c];
+          s_cnt[ww][c] = (unsigned short)run;
+          run += v;
+        }
+        tot[j] = run;
+      }
+      const unsigned both = tot[0] + tot[1];
+      const unsigned inc = wave_incl_scan(both, lane);
+      if (lane == kWave - 1) s_scan[w] = inc;
+      __syncthreads();
+      unsigned pre = inc - both;
+#pragma unroll
+      for (int ww = 0; ww < kFinWaves; ++ww)
+        if (ww < w) pre += s_scan[ww];
+      s_cstart[2 * tid] = (unsigned short)pre;
+      s_cstart[2 * tid + 1] = (unsigned short)(pre + tot[0]);
+      s_ctot[2 * tid] = (unsigned short)tot[0];
+      s_ctot[2 * tid + 1] = (unsigned short)tot[1];
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (!ok[k]) continue;
+        const unsigned d = __float_as_uint(r[k].w) & cmask;
+        s_rec[(unsigned)s_cstart[d] + (unsigned)s_cnt[w][d] + (unsigned)rank[k]] = r[k];
+      }
+      // the next tile's records: on their way while the chains run
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const unsigned i = t0 + (unsigned)kFinTile + (unsigned)(w * (kWave * 8) + k * kWave + lane);
+        ok[k] = i < hi;
+        r[k] = ok[k] ? rec[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      __syncthreads();
+      // one chain per cell
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c = tid + j * kFinThreads;
+        const unsigned s = s_cstart[c], e = s + (unsigned)s_ctot[c];
+        for (unsigned p = s; p < e; p += 4u) {
+          const float4 q0 = s_rec[p];
+          const float4 q1 = s_rec[min(p + 1u, e - 1u)];
+          const float4 q2 = s_rec[min(p + 2u, e - 1u)];
+          const float4 q3 = s_rec[min(p + 3u, e - 1u)];
+          ax[j] = ax[j] + q0.x;
+          ay[j] = ay[j] + q0.y;
+          az[j] = az[j] + q0.z;
+          if (p + 1u < e) {
+            ax[j] = ax[j] + q1.x;
+            ay[j] = ay[j] + q1.y;
+            az[j] = az[j] + q1.z;
+          }
+          if (p + 2u < e) {
+            ax[j] = ax[j] + q2.x;
+            ay[j] = ay[j] + q2.y;
+            az[j] = az[j] + q2.z;
+          }
+          if (p + 3u < e) {
+            ax[j] = ax[j] + q3.x;
+            ay[j] = ay[j] + q3.y;
+            az[j] = az[j] + q3.z;
+          }
+        }
+        an[j] += e - s;
+      }
+      // (the next tile's first barrier keeps its LDS writes behind these reads)
     }
-  }
-  __builtin_amdgcn_wave_barrier();
-  // occupied cells in ascending order: lane l owns cells [kPer l, kPer l + kPer)
-  unsigned occ = 0u;
+    // occupied cells in ascending order: cells [0, 256) by tid, then cells [256, 512)
+    unsigned base = lo;
 #pragma unroll
-  for (int j = 0; j < kPer; ++j) occ += an[lane * kPer + j] ? 1u : 0u;
-  unsigned inc = occ;
+    for (int j = 0; j < 2; ++j) {
+      const bool occ = an[j] != 0u;
+      const unsigned long long m = __ballot(occ);
+      __syncthreads();  // (s_scan: the readers of the previous use are done)
+      if (lane == 0) s_scan[w] = (unsigned)__popcll(m);
+      __syncthreads();
+      unsigned pos = base + (unsigned)__popcll(m & lt);
+      unsigned all = 0u;
 #pragma unroll
-  for (int o = 1; o < kWave; o <<= 1) {
-    const unsigned t = (unsigned)__shfl_up((int)inc, o);
-    if (lane >= o) inc += t;
-  }
-  unsigned at = r_lo + inc - occ;
-#pragma unroll
-  for (int j = 0; j < kPer; ++j) {
-    const int c = lane * kPer + j;
-    const unsigned n = an[c];
-    if (n) {
-      const float fn = (float)n;
-      out[at++] = make_float4(ax[c] / fn, ay[c] / fn, az[c] / fn, 0.f);
+      for (int ww = 0; ww < kFinWaves; ++ww) {
+        const unsigned t = s_scan[ww];
+        if (ww < w) pos += t;
+        all += t;
+      }
+      if (occ) {
+        const float fn = (float)an[j];
+        out[pos] = make_float4(ax[j] / fn, ay[j] / fn, az[j] / fn, 0.f);
+      }
+      base += all;
     }
+    if (tid == 0) vox_cnt[b] = base - lo;
   }
-  if (lane == kWave - 1) vox_cnt[b] = inc;
 }
 
 // n_vox of the call and of frame 0 from the scanned bucket counts (vox_off[n_buckets] = total)
