@@ -72,3 +72,37 @@ def test_one_cloud_on_two_ranks_hip(oracle_lib, scene, path):
     assert got[0][5] == want                                               # the merged records and labels, rank 0
     if scene != "ramp":
         assert min(got[0][2]) > 0                                          # both bands did part of A6 and A8
+
+
+def _bench_line(extra, env_extra):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--frames", "8",
+           "--points", "400000", "--no-cpu-baseline", "--no-stream"] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks():
+    """bench.py --gpus 2 without a launcher: the parent starts two ranks (here both on device 0, collectives over gloo:
+    RCCL refuses two ranks on one device), rank 0 prints one line with the frames headline and the sharded cloud."""
+    one = _bench_line(["--gpus", "1"], {})
+    two = _bench_line(["--gpus", "2"], {"HOPE_BENCH_RANKS_ON_GPU0": "1", "HOPE_BENCH_BACKEND": "gloo"})
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["scaling"] == "weak" and two["cloud"]["scaling"] == "strong"
+    assert two["cloud"]["exchange"]["path"] in ("z-bands", "replicated")
+    assert two["cloud"]["exchange"]["ranks_seen"] == 2
+    assert two["cloud"]["planes"] == one["cloud"]["planes"] > 0
+    assert two["cloud"]["points_downsampled"] == one["cloud"]["points_downsampled"]
+    assert two["points_raw_per_step"] > one["points_raw_per_step"]       # two ranks, 8 frames each
+    for line in (one, two):
+        for key in ("roofline", "stages", "ms_per_step", "value"):
+            assert key in line and key in line["cloud"]
