@@ -24,6 +24,7 @@
 #include "hull.hpp"
 #include "verify_big.hpp"
 #include "voxel_part.hpp"
+#include "grid_index.hpp"
 
 using namespace hope;
 
@@ -210,6 +211,8 @@ struct hope_ctx {
   int tile_side = 0;          // neighbour tiles: 0 = chosen per call from the points per super tile; HOPE_DEBUG_TILE_SIDE=16|32 forces
   int voxel_part = 1;         // one cloud: A5 by stable partition passes + one wave per 512-cell bucket (voxel_part.hpp;
                               // HOPE_DEBUG_VOXEL_PART=0: keys, radix sort, run lengths, k_centroids_w)
+  int grid_index = 1;         // one cloud: A6 over the 3-D occupancy index (grid_index.hpp; HOPE_DEBUG_GRID_INDEX=0: column index)
+  int grid_off_once = 0;      // ... not for the call under way: its derived cells do not ascend (set by stage_rest)
   int voxel_rank = 1;         // depth batches: voxels ranked by an LDS bitmap per frame instead of sorting the group
                               // records (HOPE_DEBUG_VOXEL_RANK=0, or any knob that asks for a sort: the sorting path)
   uint32_t* d_grp_cnt = nullptr;  // depth path: groups per chunk, then its exclusive scan
@@ -876,9 +879,26 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   const int czbits = col_only ? 0 : zbits;
   const int ckey_bits = key2_bits - zbits + czbits;
   size_t pm = prof_mark(c);
-  // frames whose column table fits in LDS (and that are not one huge cloud for a single workgroup): a counting
-  // sort per frame (k_column_index) instead of keys + device-wide radix sort + table + gather
-  if (col_only && c->col_index_lds && c->h_glob->max_cols <= kCntCap && (size_t)n_vox <= (size_t)200000 * F) {
+  // one cloud in VoxelGrid order: A6 over the 3-D occupancy index (grid_index.hpp), no column index of all points
+  const bool use_grid = c->grid_index && !c->grid_off_once && F == 1 && c->normals_direct && !c->inj_normals &&
+                        !(c->h_glob->any_overflow & 1u) && c->h_glob->max_cells <= kGridMaxCells &&
+                        c->ring <= kGridMaxRing && c->ablate == 0 && n_vox > 0;
+  uint2* grid_tab = nullptr;
+  if (use_grid) {
+    const unsigned n_words = (unsigned)(c->h_glob->max_cells / 32ull) + 2u;
+    uint32_t *gcnt, *gsums;
+    ALLOC(grid_tab, uint2, n_words);
+    ALLOC(gcnt, uint32_t, (size_t)n_words + 4);
+    ALLOC(gsums, uint32_t, scan_sums_words(n_words));
+    HIPCHK(hipMemsetAsync(grid_tab, 0, sizeof(uint2) * (size_t)n_words, s));
+    HIPCHK(hipMemsetAsync(&c->d_glob->grid_unsorted, 0, sizeof(unsigned), s));
+    hipLaunchKernelGGL(k_grid_mark, dim3(nblk(n_vox)), dim3(kBlock), 0, s, (const float4*)d_vox, n_vox, c->d_fi, c->inv_xy,
+                       c->inv_z, grid_tab, c->d_glob);
+    hipLaunchKernelGGL(k_grid_popc, dim3(nblk(n_words)), dim3(kBlock), 0, s, (const uint2*)grid_tab, n_words, gcnt);
+    scan_exclusive_u32(gcnt, gcnt, n_words, gsums, s);
+    hipLaunchKernelGGL(k_grid_pref, dim3(nblk(n_words)), dim3(kBlock), 0, s, grid_tab, n_words, (const uint32_t*)gcnt);
+    prof_close(c, ST_COLTABLE, pm, 16.0 * n_vox + 8.0 * n_words);
+  } else if (col_only && c->col_index_lds && c->h_glob->max_cols <= kCntCap && (size_t)n_vox <= (size_t)200000 * F) {
     hipLaunchKernelGGL(k_column_index, dim3(F), dim3(kRankBlock), 0, s, d_vox, c->d_fi, F, c->inv_xy, n_vox, total_cols,
                        col_first, cv_in, spt);
     prof_close(c, ST_COLTABLE, pm, (16.0 + 16.0) * n_vox + 4.0 * total_cols);
@@ -928,6 +948,17 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   if (c->inj_normals) {
     HIPCHK(hipMemcpyAsync(d_normals, c->inj_normals, sizeof(float4) * (size_t)n_vox,
                           c->inj_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+  } else if (use_grid) {
+    gate_fused = c->own_lo == 0u && c->own_hi == 0xffffffffu;
+    uint32_t* ff = gate_fused ? flags : nullptr;
+    if (c->normals_cap_small)
+      hipLaunchKernelGGL((k_normals_grid<2>), dim3(nblk(n_vox)), dim3(kBlock), 0, s, (const float4*)d_vox,
+                         (const uint2*)grid_tab, c->d_fi, c->inv_xy, c->inv_z, c->radius, c->r2, c->ring, c->own_lo,
+                         c->own_hi, (unsigned)n_vox, d_normals, c->th_norm, ff);
+    else
+      hipLaunchKernelGGL((k_normals_grid<kNbCap>), dim3(nblk(n_vox)), dim3(kBlock), 0, s, (const float4*)d_vox,
+                         (const uint2*)grid_tab, c->d_fi, c->inv_xy, c->inv_z, c->radius, c->r2, c->ring, c->own_lo,
+                         c->own_hi, (unsigned)n_vox, d_normals, c->th_norm, ff);
   } else if (c->normals_direct) {
     const int* vf = F == 1 ? nullptr : d_vox_frame;
     gate_fused = c->own_lo == 0u && c->own_hi == 0xffffffffu && c->ablate == 0;
@@ -952,7 +983,22 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
 #undef HOPE_NORMALS
   }
   prof_close(c, ST_NORMALS, pm, (16.0 + 16.0) * n_vox);
-  if (c->stop_stage == 1) return HOPE_OK;
+  // the derived cells did not ascend (a centroid rounded across a cell face; an adopted cloud that is no VoxelGrid
+  // output): the occupancy index does not describe this cloud -- the same call again over the column index
+  const auto grid_retry = [&]() {
+    c->grid_off_once = 1;
+    const int st = stage_rest<CK>(c, d_vox, d_vox_frame, zbits, key2_bits);
+    c->grid_off_once = 0;
+    return st;
+  };
+  if (c->stop_stage == 1) {
+    if (use_grid) {
+      int st = sync_globals(c);
+      if (st != HOPE_OK) return st;
+      if (c->h_glob->grid_unsorted) return grid_retry();
+    }
+    return HOPE_OK;
+  }
   // ---- A7 gate + compaction ---------------------------------------------------------
   uint32_t* fscan;
   ALLOC(fscan, uint32_t, (size_t)n_vox + 1);
@@ -968,6 +1014,7 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
     int st = sync_globals(c);  // n_fit (pad) and the largest per-frame count (max_fit)
     if (st != HOPE_OK) return st;
   }
+  if (use_grid && c->h_glob->grid_unsorted) return grid_retry();
   uint32_t* h_cnt = reinterpret_cast<uint32_t*>(&c->h_glob->pad);
   const unsigned n_fit = *h_cnt;
   const unsigned max_fit = c->h_glob->max_fit;
@@ -1005,6 +1052,21 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   ALLOC(col_first_fit, uint32_t, (size_t)total_cols + 1);
   ALLOC(spt_fit, float4, n_fit);
   pm = prof_mark(c);
+  if (use_grid) {
+    // the fit points are in VoxelGrid order (z cell, then y, then x): a stable sort by column alone leaves every
+    // column ascending in z cell; 12x fewer points than the whole down-sampled cloud on the 1e8-point scene
+    hipLaunchKernelGGL((k_column_keys<CK>), dim3(nblk(n_fit)), dim3(kBlock), 0, s, (const float4*)fit_pt,
+                       (const int*)fit_frame, c->d_fi, n_fit, c->inv_xy, c->inv_z, 0, ck_in, cv_in);
+    if (sizeof(CK) == 4) {
+      HIPCHK(sort_pairs_u32(pa, (const uint32_t*)ck_in, (uint32_t*)ck_out, cv_in, cv_out, n_fit, key2_bits - zbits, s));
+    } else {
+      HIPCHK(sort_pairs_u64(pa, (const uint64_t*)ck_in, (uint64_t*)ck_out, cv_in, cv_out, n_fit, key2_bits - zbits, s));
+    }
+    hipLaunchKernelGGL((k_column_table<CK>), dim3(nblk((size_t)n_fit + 1)), dim3(kBlock), 0, s, ck_out, n_fit, total_cols,
+                       0, col_first_fit);
+    hipLaunchKernelGGL(k_gather_coarse, dim3(nblk(n_fit)), dim3(kBlock), 0, s, (const float4*)fit_pt, cv_out, n_fit,
+                       spt_fit);
+  } else {
   if (!gate_fused)
     hipLaunchKernelGGL(k_fit_sorted_flags, dim3(nblk((size_t)n_vox + 1)), dim3(kBlock), 0, s, spt, fit_rank, n_vox,
                        sflags);
@@ -1013,6 +1075,7 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
                      spt_fit);
   hipLaunchKernelGGL(k_fit_col_table, dim3(nblk((size_t)total_cols + 1)), dim3(kBlock), 0, s, col_first, fpos,
                      total_cols, col_first_fit);
+  }
   prof_close(c, ST_FITIDX, pm, (16.0 + 4.0 + 4.0 + 8.0 + 8.0) * n_vox + 32.0 * (double)n_fit + 8.0 * total_cols);
   pm = prof_mark(c);
   HIPCHK(hipMemsetAsync(&c->d_glob->n_todo, 0, sizeof(unsigned), s));
@@ -1524,6 +1587,8 @@ HOPE_API int hope_create(const hope_config* cfg, hope_ctx** out)
   }
   knob = std::getenv("HOPE_DEBUG_VOXEL_PART");
   c->voxel_part = (knob && knob[0] == '0') ? 0 : 1;
+  knob = std::getenv("HOPE_DEBUG_GRID_INDEX");
+  c->grid_index = (knob && knob[0] == '0') ? 0 : 1;
   knob = std::getenv("HOPE_DEBUG_VERIFY_BIG");
   if (knob) c->verify_big_from = std::atoi(knob);
   knob = std::getenv("HOPE_DEBUG_VOXEL_RANK");

@@ -63,6 +63,7 @@ struct Globals {  // scalars produced on device, read back at the sync points
   unsigned int max_vox;        // k_frame_vox_scan: largest per-frame count of voxels
   unsigned int n_big;          // k_big_count: clusters of verify_big_from members and more ...
   unsigned int n_big_sb;       // ... and their 1024-member super blocks (verify_big.hpp)
+  unsigned int grid_unsorted;  // k_grid_mark: the derived cells do not strictly ascend along the down-sampled cloud
 };
 
 struct DepthSrc {

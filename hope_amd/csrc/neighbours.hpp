@@ -764,6 +764,40 @@ __device__ __forceinline__ void accumulate_sorted(const Cols& cols, const float4
 }
 #undef HOPE_CE
 
+// the normal of a point from the nine sums over its neighbours (computeMeanAndCovarianceMatrix's tail, pcl::eigen33's
+// smallest eigenvector, curvature, flipNormalTowardsViewpoint towards the origin: PCL 1.8.1 centroid.hpp, normal_3d.h)
+__device__ __forceinline__ float4 normal_from_sums(float* accu, int total, const float4 q)
+{
+  const float cnt = (float)total;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) accu[k] /= cnt;
+  float cov[9];
+  cov[0] = accu[0] - accu[6] * accu[6];
+  cov[1] = accu[1] - accu[6] * accu[7];
+  cov[2] = accu[2] - accu[6] * accu[8];
+  cov[4] = accu[3] - accu[7] * accu[7];
+  cov[5] = accu[4] - accu[7] * accu[8];
+  cov[8] = accu[5] - accu[8] * accu[8];
+  cov[3] = cov[1];
+  cov[6] = cov[2];
+  cov[7] = cov[5];
+  float eval, evec[3];
+  eigen33_smallest(cov, eval, evec);
+  float nx = evec[0], ny = evec[1], nz = evec[2];
+  const float eig_sum = cov[0] + cov[4] + cov[8];
+  float curvature = 0.f;
+  if (eig_sum != 0.f) curvature = fabsf(eval / eig_sum);
+  // flipNormalTowardsViewpoint(point, 0, 0, 0, ...)   (PCL 1.8.1 normal_3d.h)
+  const float vpx = 0.f - q.x, vpy = 0.f - q.y, vpz = 0.f - q.z;
+  const float cos_theta = (vpx * nx + vpy * ny + vpz * nz);
+  if (cos_theta < 0.f) {
+    nx *= -1.f;
+    ny *= -1.f;
+    nz *= -1.f;
+  }
+  return make_float4(nx, ny, nz, curvature);
+}
+
 // columns / rows of the stencil that can hold a point within `radius` of q (see estimate_normal)
 __device__ __forceinline__ void stencil_reach(const float4 q, int ring, float radius, float inv_xy, float slack, int& kl,
                                               int& kr, int& kd, int& ku)
@@ -819,35 +853,13 @@ __device__ __forceinline__ float4 estimate_normal(const Cols& cols, const float4
   } else {
     accumulate_by_rescan(cols, q, x0, x1, y0, y1, zlo, zhi, r2, total, accu);
   }
-  const float cnt = (float)total;
+  if (ablate == 3) {
+    const float cnt = (float)total;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) accu[k] /= cnt;
-  if (ablate == 3) return make_float4(accu[0] + accu[1] + accu[2], accu[3] + accu[4] + accu[5], accu[6] + accu[7], accu[8]);
-  float cov[9];
-  cov[0] = accu[0] - accu[6] * accu[6];
-  cov[1] = accu[1] - accu[6] * accu[7];
-  cov[2] = accu[2] - accu[6] * accu[8];
-  cov[4] = accu[3] - accu[7] * accu[7];
-  cov[5] = accu[4] - accu[7] * accu[8];
-  cov[8] = accu[5] - accu[8] * accu[8];
-  cov[3] = cov[1];
-  cov[6] = cov[2];
-  cov[7] = cov[5];
-  float eval, evec[3];
-  eigen33_smallest(cov, eval, evec);
-  float nx = evec[0], ny = evec[1], nz = evec[2];
-  const float eig_sum = cov[0] + cov[4] + cov[8];
-  float curvature = 0.f;
-  if (eig_sum != 0.f) curvature = fabsf(eval / eig_sum);
-  // flipNormalTowardsViewpoint(point, 0, 0, 0, ...)   (PCL 1.8.1 normal_3d.h)
-  const float vpx = 0.f - q.x, vpy = 0.f - q.y, vpz = 0.f - q.z;
-  const float cos_theta = (vpx * nx + vpy * ny + vpz * nz);
-  if (cos_theta < 0.f) {
-    nx *= -1.f;
-    ny *= -1.f;
-    nz *= -1.f;
+    for (int k = 0; k < 9; ++k) accu[k] /= cnt;
+    return make_float4(accu[0] + accu[1] + accu[2], accu[3] + accu[4] + accu[5], accu[6] + accu[7], accu[8]);
   }
-  return make_float4(nx, ny, nz, curvature);
+  return normal_from_sums(accu, total, q);
 }
 
 // grid = (max tiles per frame, n_frames)

@@ -689,6 +689,34 @@ def test_staged_cloud_entry_points(hip_lib, oracle_lib):
     assert ref.clusters(0).tobytes() == g.clusters(0).tobytes()
 
 
+def test_cloud_normals_over_the_occupancy_index_or_the_column_index(hip_lib, oracle_lib, monkeypatch):
+    """A6 of a single cloud over the 3-D occupancy index (grid_index.hpp, the default) and over the column index
+    (HOPE_DEBUG_GRID_INDEX=0); with neighbour lists longer than the ordering networks (cap of 2: one scan per pick);
+    and on an adopted cloud that is NO VoxelGrid output (several points per cell, input order): the library notices
+    that the derived cells do not ascend and takes the column index for that call."""
+    from hope_amd import synth
+    mid = synth.make_multilevel_cloud(400000, first_index=31, device="cpu").numpy()
+    loft = np.load(os.path.join(GOLDEN, "loft_120k.npz"))["xyz"]
+    o = HopeContext(oracle_lib)
+    for env in ({}, {"HOPE_DEBUG_GRID_INDEX": "0"}, {"HOPE_DEBUG_SMALL_NB_CAP": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g = HopeContext(hip_lib)
+        for k in env:
+            monkeypatch.delenv(k)
+        for xyz in (mid, loft):
+            for c in (g, o):
+                assert c.segment_cloud(xyz) == 0
+            assert_frame_equal(o, g, 0)
+        # adopted as it is: a raw cloud, many points per cell, in input order
+        raw = np.ascontiguousarray(mid[:60000] * np.float32(0.2))
+        gb = np.concatenate([raw.min(0), raw.max(0)]).astype(np.float32)
+        for c in (g, o):
+            c.segment_downsampled(raw.ctypes.data, raw.shape[0], 12, False, gb, raw.shape[0])
+        assert summary(g, 0) == summary(o, 0)
+        assert np.array_equal(o.normals(0), g.normals(0), equal_nan=True) and np.array_equal(o.knn(0), g.knn(0))
+
+
 def test_division_by_camera_constants(hip_lib, oracle_lib, monkeypatch):
     """A1's divisions by depth_scale / fx / fy run as a 3-instruction sequence once the library has
     checked it against the IEEE quotient for every possible dividend; the knob forces IEEE divisions.

@@ -12,6 +12,7 @@
 #include <numeric>
 #include <vector>
 #include "voxel_part.hpp"
+#include "grid_index.hpp"
 using namespace hope;
 
 struct Shelf { float x0, x1, y0, y1, z; };
@@ -173,6 +174,67 @@ int main(int argc, char** argv)
       }
     printf(bad ? "MISMATCH: %zu components differ\n" : "check: bit-exact (%zu)\n", bad);
     if (bad) return 1;
+  }
+  // ---- A6 over the occupancy index (grid_index.hpp) on the voxels just made
+  {
+    hfi.slack = 30.f * 20.f * 2.4e-7f + 1e-6f; hfi.n_raw = (int)N;
+    CK(hipMemcpy(fi, &hfi, sizeof(hfi), hipMemcpyHostToDevice));
+    const unsigned n_vox = hg.n_vox_total, n_words = (unsigned)(max_cells / 32ull) + 2u;
+    uint2* tab; uint32_t *gcnt, *gsums, *flags; float4* normals;
+    CK(hipMalloc(&tab, 8ull * n_words)); CK(hipMalloc(&gcnt, 4ull * (n_words + 4))); CK(hipMalloc(&gsums, 4 * scan_sums_words(n_words)));
+    CK(hipMalloc(&flags, 4ull * (n_vox + 1))); CK(hipMalloc(&normals, 16ull * n_vox));
+    const float radius = (float)(1.01 * 0.05), r2 = (float)((double)radius * (double)radius);
+    hipEvent_t g0, g1, g2;
+    hipEventCreate(&g0); hipEventCreate(&g1); hipEventCreate(&g2);
+    for (int rep = 0; rep < 3; ++rep) {
+      hipEventRecord(g0, 0);
+      hipMemsetAsync(tab, 0, 8ull * n_words, 0);
+      hipLaunchKernelGGL(k_grid_mark, dim3((n_vox + kBlock - 1) / kBlock), dim3(kBlock), 0, 0, (const float4*)vox, n_vox, fi, inv_xy, inv_z, tab, glob);
+      hipLaunchKernelGGL(k_grid_popc, dim3((n_words + kBlock - 1) / kBlock), dim3(kBlock), 0, 0, (const uint2*)tab, n_words, gcnt);
+      scan_exclusive_u32(gcnt, gcnt, n_words, gsums, 0);
+      hipLaunchKernelGGL(k_grid_pref, dim3((n_words + kBlock - 1) / kBlock), dim3(kBlock), 0, 0, tab, n_words, (const uint32_t*)gcnt);
+      hipEventRecord(g1, 0);
+      hipLaunchKernelGGL((k_normals_grid<kNbCap>), dim3((n_vox + kBlock - 1) / kBlock), dim3(kBlock), 0, 0, (const float4*)vox, (const uint2*)tab, fi, inv_xy, inv_z, radius, r2, 2, 0u, 0xffffffffu, n_vox, normals, 0.87039f, flags);
+      hipEventRecord(g2, 0);
+      CK(hipDeviceSynchronize());
+      float a, b; hipEventElapsedTime(&a, g0, g1); hipEventElapsedTime(&b, g1, g2);
+      printf("grid build %.3f ms, k_normals_grid %.3f ms", a, b);
+      hipEventRecord(g1, 0);
+      hipLaunchKernelGGL((k_normals_grid<kNbCap, 1>), dim3((n_vox + kBlock - 1) / kBlock), dim3(kBlock), 0, 0, (const float4*)vox, (const uint2*)tab, fi, inv_xy, inv_z, radius, r2, 2, 0u, 0xffffffffu, n_vox, normals, 0.87039f, (uint32_t*)nullptr);
+      hipEventRecord(g2, 0);
+      CK(hipDeviceSynchronize());
+      hipEventElapsedTime(&b, g1, g2);
+      printf(", scan only %.3f ms", b);
+      if (rep == 0) {
+        std::vector<float> hn(4ull * n_vox); CK(hipMemcpy(hn.data(), normals, 16ull * n_vox, hipMemcpyDeviceToHost));
+        size_t hist[7] = {0, 0, 0, 0, 0, 0, 0}, lanes[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (size_t w0 = 0; w0 < n_vox; w0 += 64) {
+          int mx = 0, act = 0;
+          for (size_t i = w0; i < std::min<size_t>(w0 + 64, n_vox); ++i) { const int t = (int)hn[4 * i]; mx = std::max(mx, t); act += t >= 3; }
+          const int b = mx < 3 ? 0 : mx <= 8 ? 1 : mx <= 12 ? 2 : mx <= 16 ? 3 : mx <= 32 ? 4 : 5;
+          ++hist[b]; lanes[b] += act;
+        }
+        printf("\n  waves by longest list: <3: %zu, <=8: %zu (%zu lanes), <=12: %zu (%zu), <=16: %zu (%zu), <=32: %zu (%zu), more: %zu (%zu)\n  ",
+               hist[0], hist[1], lanes[1], hist[2], lanes[2], hist[3], lanes[3], hist[4], lanes[4], hist[5], lanes[5]);
+      }
+      hipEventRecord(g1, 0);
+      hipLaunchKernelGGL((k_normals_grid<kNbCap, 2>), dim3((n_vox + kBlock - 1) / kBlock), dim3(kBlock), 0, 0, (const float4*)vox, (const uint2*)tab, fi, inv_xy, inv_z, radius, r2, 2, 0u, 0xffffffffu, n_vox, normals, 0.87039f, (uint32_t*)nullptr);
+      hipEventRecord(g2, 0);
+      CK(hipDeviceSynchronize());
+      hipEventElapsedTime(&b, g1, g2);
+      printf(", without the eigen solver %.3f ms\n", b);
+#define TRY(NAME, ...)                                                                                                  \
+      hipEventRecord(g1, 0);                                                                                            \
+      hipLaunchKernelGGL((k_normals_grid<__VA_ARGS__>), dim3((n_vox + kBlock - 1) / kBlock), dim3(kBlock), 0, 0, (const float4*)vox, (const uint2*)tab, fi, inv_xy, inv_z, radius, r2, 2, 0u, 0xffffffffu, n_vox, normals, 0.87039f, (uint32_t*)nullptr); \
+      hipEventRecord(g2, 0);                                                                                            \
+      CK(hipDeviceSynchronize());                                                                                       \
+      hipEventElapsedTime(&b, g1, g2);                                                                                  \
+      printf("   %s %.3f ms\n", NAME, b);
+    }
+    CK(hipMemcpy(&hg, glob, sizeof(hg), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> hf(n_vox); CK(hipMemcpy(hf.data(), flags, 4ull * n_vox, hipMemcpyDeviceToHost));
+    size_t nf = 0; for (auto f : hf) nf += f;
+    printf("grid_unsorted %u, fit %zu of %u\n", hg.grid_unsorted, nf, n_vox);
   }
   for (int rep = 0; rep < 2; ++rep) {
     run(true);
