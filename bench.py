@@ -64,6 +64,9 @@ def parse_args():
     ap.add_argument("--no-cloud", action="store_true", help="frames workload: leave out the cloud sub-object")
     ap.add_argument("--no-stream", action="store_true", help="frames workload: leave out the stream sub-object")
     ap.add_argument("--stream-frames", type=int, default=300)
+    ap.add_argument("--sub-batches", type=int, default=0,
+                    help="frames workload: hope_config.sub_batches (frame ranges on streams of their own; the per-stage "
+                         "times then overlap and describe no kernel running alone)")
     ap.add_argument("--hip-lib", default=None, help="diagnostics only: another build of libhope_hip.so (tools/ablate.sh)")
     return ap.parse_args()
 
@@ -282,7 +285,7 @@ def run_frames(job):
     import numpy as np
     from hope_amd import synth
     torch, args = job.torch, job.args
-    ctx = job.new_ctx()
+    ctx = job.new_ctx(sub_batches=args.sub_batches)
     F = args.frames
     depth = torch.empty((F, H, W), dtype=torch.uint16, device=job.dev)
     ts, qs = [], []

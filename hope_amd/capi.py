@@ -28,8 +28,8 @@ class HopeConfig(C.Structure):
         ("depth_scale", C.c_float),
         ("knn", C.c_int32), ("min_cluster", C.c_int32), ("mode", C.c_int32),
         ("min_height", C.c_float), ("max_height", C.c_float),
-        ("aggressive_merge", C.c_int32), ("device", C.c_int32),
-        ("reserved", C.c_int32 * 4),
+        ("aggressive_merge", C.c_int32), ("device", C.c_int32), ("sub_batches", C.c_int32),
+        ("reserved", C.c_int32 * 3),
     ]
 
 

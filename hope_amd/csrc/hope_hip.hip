@@ -131,11 +131,11 @@ inline unsigned nblk(size_t n, int per = kBlock) { return (unsigned)((n + per - 
 // Optional per-stage timing with HIP events recorded on the ctx stream (bench.py's roofline
 // figures come from here; off by default).
 enum Stage {
-  ST_BBOX, ST_GRID, ST_VKEYS, ST_VSORT, ST_VRLE, ST_VRANK, ST_VPART, ST_VFINISH, ST_CENTROID, ST_COLKEYS, ST_COLSORT, ST_COLTABLE, ST_NORMALS,
+  ST_BBOX, ST_GRID, ST_VKEYS, ST_VSORT, ST_VRLE, ST_VRANK, ST_VPCOUNT, ST_VPART, ST_VFINISH, ST_CENTROID, ST_COLKEYS, ST_COLSORT, ST_COLTABLE, ST_NORMALS,
   ST_FIT, ST_FITIDX, ST_KNN, ST_KNN_TODO, ST_LABELS, ST_SEGMENTS, ST_VERIFY, ST_COUNT
 };
 const char* const kStageNames[ST_COUNT] = {
-  "k_bbox", "k_frame_grid", "k_voxel_keys", "voxel_sort(rocprim)", "voxel_rle+scan(rocprim)", "k_voxel_rank", "k_part_count+scatter", "k_part_finish", "k_centroids",
+  "k_bbox", "k_frame_grid", "k_voxel_keys", "voxel_sort(rocprim)", "voxel_rle+scan(rocprim)", "k_voxel_rank", "k_part_count", "k_part_scatter", "k_part_finish", "k_centroids",
   "k_column_keys", "column_sort(rocprim)", "k_column_table+gather", "k_normals", "fit_gate+compact", "fit_column_index", "k_knn",
   "k_knn_todo",
   "labels(union+sweeps)", "segments(scan+sort)", "k_cluster_verify"};
@@ -257,7 +257,7 @@ struct hope_ctx {
   // by a child context of its own (own stream, own workspace) on a host thread of its own: while one
   // range waits for a count to come back or runs a kernel that cannot fill the chip (a chain of
   // dependent adds, one workgroup per frame), the kernels of the other ranges use the idle CUs.
-  int n_sub = 1;                  // HOPE_SUB_BATCHES (1: never split).  Measured on MI355X, 1024 frames: four ranges
+  int n_sub = 1;                  // hope_config::sub_batches (1: never split).  Measured on MI355X, 1024 frames: four ranges
                                   // 13.7 ms against 12.3 ms unsplit -- the kernels already fill the chip -- so off by default
   int sub_min_frames = 64;        // HOPE_DEBUG_SUB_MIN: frames per range below which a batch is not cut further
   std::vector<hope_ctx*> kids;
@@ -632,34 +632,43 @@ int stage_voxel_part(hope_ctx* c, const Src& src, size_t N, int cell_bits, float
   ALLOC(vox_cnt, uint32_t, (size_t)n_buckets + 4);
   ALLOC(big, uint32_t, (size_t)n_buckets + 4);
   ALLOC(big_n, uint32_t, 4);
-  size_t pm = prof_mark(c);
+  // algorithmic bytes of a kernel = its input read once + its output written once: the count of a pass needs the
+  // point (first pass) or the 4-byte cell of a record; a scatter pass reads the point or the 16-byte record and
+  // writes the 16-byte record
+  size_t pm;
   int cur = 0, shift = kPartLow;
   for (int p = 0; p < n_pass; ++p) {
     const int bits = high / n_pass + (p < high % n_pass ? 1 : 0);
     const size_t n_cnt = ((size_t)1 << bits) * n_chunks;
+    pm = prof_mark(c);
     if (p == 0) {
       hipLaunchKernelGGL((k_part_count<true, Src>), dim3(n_chunks), dim3(kBlock), 0, s, src, c->d_fi, c->inv_xy, c->inv_z,
                          (const float4*)nullptr, (unsigned)N, shift, bits, counts, n_chunks);
       scan_exclusive_u32(counts, counts, n_cnt, sums, s);
+      prof_close(c, ST_VPCOUNT, pm, src_point_bytes(src) * (double)N + 8.0 * n_cnt);
+      pm = prof_mark(c);
       hipLaunchKernelGGL((k_part_scatter<true, Src>), dim3(n_chunks), dim3(kPartThreads), 0, s, src, c->d_fi, c->inv_xy,
                          c->inv_z, (const float4*)nullptr, (unsigned)N, shift, bits, (const uint32_t*)counts, n_chunks,
                          buf[0]);
+      prof_close(c, ST_VPART, pm, (src_point_bytes(src) + 16.0) * (double)N);
       cur = 0;
     } else {
       hipLaunchKernelGGL((k_part_count<false, Src>), dim3(n_chunks), dim3(kBlock), 0, s, src, c->d_fi, c->inv_xy,
                          c->inv_z, (const float4*)buf[cur], (unsigned)N, shift, bits, counts, n_chunks);
       scan_exclusive_u32(counts, counts, n_cnt, sums, s);
+      prof_close(c, ST_VPCOUNT, pm, 4.0 * (double)N + 8.0 * n_cnt);
+      pm = prof_mark(c);
       hipLaunchKernelGGL((k_part_scatter<false, Src>), dim3(n_chunks), dim3(kPartThreads), 0, s, src, c->d_fi, c->inv_xy,
                          c->inv_z, (const float4*)buf[cur], (unsigned)N, shift, bits, (const uint32_t*)counts, n_chunks,
                          buf[cur ^ 1]);
+      prof_close(c, ST_VPART, pm, 32.0 * (double)N);
       cur ^= 1;
     }
     shift += bits;
   }
+  pm = prof_mark(c);
   hipLaunchKernelGGL(k_part_bounds, dim3(nblk((size_t)n_buckets + 1)), dim3(kBlock), 0, s, (const float4*)buf[cur],
                      c->d_fi, n_buckets, bstart);
-  prof_close(c, ST_VPART, pm, (src_point_bytes(src) + 4.0) * (double)N);
-  pm = prof_mark(c);
   float4* tmp = buf[cur ^ 1];
   HIPCHK(hipMemsetAsync(vox_cnt + n_buckets, 0, sizeof(uint32_t), s));
   HIPCHK(hipMemsetAsync(big_n, 0, 4 * sizeof(uint32_t), s));
@@ -681,7 +690,7 @@ int stage_voxel_part(hope_ctx* c, const Src& src, size_t N, int cell_bits, float
   ALLOC(d_vox_frame, int, n_vox);
   hipLaunchKernelGGL(k_part_compact, dim3(nblk(n_buckets, kBlock / kWave)), dim3(kBlock), 0, s, (const float4*)tmp,
                      (const uint32_t*)bstart, (const uint32_t*)vox_cnt, n_buckets, d_vox, d_vox_frame);
-  prof_close(c, ST_VFINISH, pm, 16.0 * n_vox);
+  prof_close(c, ST_VFINISH, pm, 16.0 * (double)N + (16.0 + 32.0) * n_vox);
   return HOPE_OK;
 }
 
@@ -1533,7 +1542,8 @@ HOPE_API int hope_create(const hope_config* cfg, hope_ctx** out)
       (void)hipGetLastError();
       c->mail_poll = 0;
     }
-    const char* sk = std::getenv("HOPE_DEBUG_SYNC");
+    const char* dk = std::getenv("HOPE_DEBUG");
+    const char* sk = (dk && dk[0] == '1') ? std::getenv("HOPE_DEBUG_SYNC") : nullptr;
     if (sk && std::strcmp(sk, "memcpy") == 0) c->mail_poll = 0;
   }
   {
@@ -1552,46 +1562,51 @@ HOPE_API int hope_create(const hope_config* cfg, hope_ctx** out)
     }
     c->d_scratch = cfg->device < kMaxDevices ? g_scratch_ptr[cfg->device] : nullptr;
   }
-  const char* knob = std::getenv("HOPE_DEBUG_SMALL_NB_CAP");
+  // Test knobs: every HOPE_DEBUG_* variable below forces a path the data rarely takes (results are the same on
+  // every path).  They are read only when HOPE_DEBUG=1 is set as well, so that a stray variable in a production
+  // environment cannot change which kernels run.
+  const char* dbg_on = std::getenv("HOPE_DEBUG");
+  const bool dbg = dbg_on && dbg_on[0] == '1';
+  const auto debug_env = [dbg](const char* name) -> const char* { return dbg ? std::getenv(name) : nullptr; };
+  if (cfg->sub_batches >= 1) c->n_sub = std::min((int)cfg->sub_batches, 16);
+  const char* knob = debug_env("HOPE_DEBUG_SMALL_NB_CAP");
   c->normals_cap_small = (knob && knob[0] == '1') ? 1 : 0;
 #ifdef HOPE_ABLATE  // timing experiments (tools/ablate.sh builds its own library): never in the shipped build
-  knob = std::getenv("HOPE_DEBUG_ABLATE");
+  knob = debug_env("HOPE_DEBUG_ABLATE");
   c->ablate = knob ? std::atoi(knob) : 0;
 #endif
-  knob = std::getenv("HOPE_DEBUG_KNN_FINE_LIMIT");
+  knob = debug_env("HOPE_DEBUG_KNN_FINE_LIMIT");
   if (knob) c->knn_fine_limit = (unsigned)std::atoll(knob);
-  knob = std::getenv("HOPE_DEBUG_IEEE_DIV");
+  knob = debug_env("HOPE_DEBUG_IEEE_DIV");
   c->force_ieee_div = (knob && knob[0] == '1') ? 1 : 0;
-  knob = std::getenv("HOPE_DEBUG_PIXEL_SORT");
+  knob = debug_env("HOPE_DEBUG_PIXEL_SORT");
   c->pixel_sort = (knob && knob[0] == '1') ? 1 : 0;
-  knob = std::getenv("HOPE_DEBUG_TWO_PASS");
+  knob = debug_env("HOPE_DEBUG_TWO_PASS");
   c->two_pass = (knob && knob[0] == '1') ? 1 : 0;
-  knob = std::getenv("HOPE_DEBUG_COLSORT_Z");
+  knob = debug_env("HOPE_DEBUG_COLSORT_Z");
   c->col_sort_z = (knob && knob[0] == '1') ? 1 : 0;
-  knob = std::getenv("HOPE_SUB_BATCHES");
-  if (knob && std::atoi(knob) >= 1) c->n_sub = std::min(std::atoi(knob), 16);
-  knob = std::getenv("HOPE_DEBUG_SUB_MIN");
+  knob = debug_env("HOPE_DEBUG_SUB_MIN");
   if (knob && std::atoi(knob) >= 1) c->sub_min_frames = std::atoi(knob);
-  knob = std::getenv("HOPE_DEBUG_SEGSORT");
+  knob = debug_env("HOPE_DEBUG_SEGSORT");
   c->seg_sort = (knob && knob[0] == '0') ? 0 : 1;
-  knob = std::getenv("HOPE_DEBUG_COL_INDEX");
+  knob = debug_env("HOPE_DEBUG_COL_INDEX");
   c->col_index_lds = (knob && knob[0] == '0') ? 0 : 1;
-  knob = std::getenv("HOPE_DEBUG_TILE_SIDE");
+  knob = debug_env("HOPE_DEBUG_TILE_SIDE");
   if (knob) c->tile_side = std::atoi(knob) == kSuper ? kSuper : (std::atoi(knob) == kTile ? kTile : 0);
-  knob = std::getenv("HOPE_DEBUG_TODO_THREADS");
+  knob = debug_env("HOPE_DEBUG_TODO_THREADS");
   if (knob) c->todo_threads = std::atoi(knob);
-  knob = std::getenv("HOPE_DEBUG_NEIGHBOURS");  // tiles | tiles-normals | tiles-knn
+  knob = debug_env("HOPE_DEBUG_NEIGHBOURS");  // tiles | tiles-normals | tiles-knn
   if (knob && std::strncmp(knob, "tiles", 5) == 0) {
     c->normals_direct = std::strcmp(knob, "tiles-knn") == 0 ? 1 : 0;
     c->knn_direct = std::strcmp(knob, "tiles-normals") == 0 ? 1 : 0;
   }
-  knob = std::getenv("HOPE_DEBUG_VOXEL_PART");
+  knob = debug_env("HOPE_DEBUG_VOXEL_PART");
   c->voxel_part = (knob && knob[0] == '0') ? 0 : 1;
-  knob = std::getenv("HOPE_DEBUG_GRID_INDEX");
+  knob = debug_env("HOPE_DEBUG_GRID_INDEX");
   c->grid_index = (knob && knob[0] == '0') ? 0 : 1;
-  knob = std::getenv("HOPE_DEBUG_VERIFY_BIG");
+  knob = debug_env("HOPE_DEBUG_VERIFY_BIG");
   if (knob) c->verify_big_from = std::atoi(knob);
-  knob = std::getenv("HOPE_DEBUG_VOXEL_RANK");
+  knob = debug_env("HOPE_DEBUG_VOXEL_RANK");
   c->voxel_rank = (knob && knob[0] == '0') ? 0 : c->seg_sort;
   *out = c;
   return HOPE_OK;

@@ -77,7 +77,10 @@ typedef struct hope_config {
   float max_height;       /* cfg/hope.cfg:15 max_height_cfg                            (1.5)  */
   int32_t aggressive_merge; /* plane_segment.cpp:719                                   (1)    */
   int32_t device;         /* HIP device ordinal (ignored by the oracle)                (0)    */
-  int32_t reserved[4];
+  int32_t sub_batches;    /* depth batches of many frames: run as up to this many frame ranges, each on a
+                             stream and host thread of its own (0 or 1: never split; no reference counterpart:
+                             src/hope_node.cpp:223-241 is one loop; ignored by the oracle)     (0)    */
+  int32_t reserved[3];
 } hope_config;
 
 /* Per-frame stage sizes. */

@@ -9,6 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# the library reads its HOPE_DEBUG_* test knobs (forced paths) only when this is set
+os.environ["HOPE_DEBUG"] = "1"
+
 ORACLE_LIB = os.path.join(ROOT, "oracle", "_build", "libhope_oracle.so")
 ORACLE_LIBM_LIB = os.path.join(ROOT, "oracle", "_build", "libhope_oracle_libm.so")
 GOLDEN = os.path.join(ROOT, "tests", "golden")

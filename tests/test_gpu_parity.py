@@ -779,7 +779,7 @@ def test_invalid_arguments(hip_lib):
 
 
 def test_sub_batches_on_their_own_streams(hip_lib, oracle_lib, monkeypatch):
-    """With HOPE_SUB_BATCHES=n a batch of many frames runs as up to n frame ranges, each in a child context with
+    """With hope_config.sub_batches = n a batch of many frames runs as up to n frame ranges, each in a child context with
     its own stream, workspace and host thread (hope_hip.hip: segment_depth_split; off by default: measured slower
     than one range on MI355X).  Forced here on 14 frames (ranges of 3-4):
     every stage of every frame equals the oracle's, the per-frame accessors and the objects-on-plane step find
@@ -787,11 +787,9 @@ def test_sub_batches_on_their_own_streams(hip_lib, oracle_lib, monkeypatch):
     from test_upon_plane import winner_contour
     import ctypes
     depth, t, q = synth_frames(14, first=40)
-    monkeypatch.setenv("HOPE_SUB_BATCHES", "4")
     monkeypatch.setenv("HOPE_DEBUG_SUB_MIN", "3")
-    g = HopeContext(hip_lib, mode=HOPE_MODE_RT, min_height=0.5, max_height=1.0)
+    g = HopeContext(hip_lib, mode=HOPE_MODE_RT, min_height=0.5, max_height=1.0, sub_batches=4)
     monkeypatch.delenv("HOPE_DEBUG_SUB_MIN")
-    monkeypatch.delenv("HOPE_SUB_BATCHES")
     o = HopeContext(oracle_lib, mode=HOPE_MODE_RT, min_height=0.5, max_height=1.0)
     for c in (g, o):
         c.set_frame_poses(t, q)
