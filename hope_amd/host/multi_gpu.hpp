@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -58,20 +59,36 @@ std::vector<int32_t> band_partition(const std::vector<int64_t>& hist, int world)
 
 // Collective: every rank calls it with its own ctx (created on its own device) and its share of the cloud in HOST
 // memory (n points, stride 12).  Returns HOPE_OK / HOPE_EMPTY / HOPE_NO_NORMAL_FIT or < 0 (text in err).
+// A library step that fails on one rank does not leave the others waiting: the statuses travel with every exchange of
+// sizes, and all ranks return at the next one (the failing rank its own status, the others HOPE_E_PEER).  A backend
+// that throws (HIP / RCCL errors) is the caller's to handle: abort the group (ThreadGroup::abort, ncclCommAbort).
+// fail_rank / fail_step: fault injection for the tests -- library step number fail_step of rank fail_rank reports
+// HOPE_E_NOMEM instead of running.
 int segment_cloud_multi(hope_ctx* ctx, Comm& comm, const float* xyz_host, size_t n, int apply_filter_transform,
-                        const hope_config& cfg, MultiResult& out, std::string& err, bool allow_bands = true);
+                        const hope_config& cfg, MultiResult& out, std::string& err, bool allow_bands = true,
+                        int fail_rank = -1, int fail_step = -1);
 
 // ---- threads on host memory -------------------------------------------------------------------------------------
 class ThreadGroup {
  public:
   explicit ThreadGroup(int world) : world_(world), ptr_(world), cnt_(world) {}
   int world() const { return world_; }
+  // throws when the group has been aborted (a rank left the collective call with an exception): nobody waits for
+  // a rank that will not come
   void barrier()
   {
     std::unique_lock<std::mutex> lk(m_);
+    if (aborted_) throw std::runtime_error("the rank group was aborted");
     const unsigned gen = gen_;
     if (++waiting_ == world_) { waiting_ = 0; ++gen_; cv_.notify_all(); }
-    else cv_.wait(lk, [&] { return gen != gen_; });
+    else cv_.wait(lk, [&] { return gen != gen_ || aborted_; });
+    if (aborted_) throw std::runtime_error("the rank group was aborted");
+  }
+  void abort()
+  {
+    std::lock_guard<std::mutex> lk(m_);
+    aborted_ = true;
+    cv_.notify_all();
   }
   std::vector<const void*>& ptr() { return ptr_; }
   std::vector<const int64_t*>& cnt() { return cnt_; }
@@ -79,6 +96,7 @@ class ThreadGroup {
  private:
   int world_, waiting_ = 0;
   unsigned gen_ = 0;
+  bool aborted_ = false;
   std::mutex m_;
   std::condition_variable cv_;
   std::vector<const void*> ptr_;

@@ -5,7 +5,9 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
 #include <thread>
 
@@ -23,9 +25,52 @@ namespace {
     if (r__ != ncclSuccess) throw std::runtime_error(std::string(#x ": ") + ncclGetErrorString(r__)); \
   } while (0)
 
+// Device buffers of a backend, kept for re-use until the backend goes away: an exchange sequence asks for some
+// twenty buffers, and hipMalloc / hipFree are device-wide synchronisations that N rank threads of one process
+// would take turns in.
+class DevicePool {
+ public:
+  explicit DevicePool(int device) : device_(device) {}
+  ~DevicePool()
+  {
+    (void)hipSetDevice(device_);
+    for (auto& b : all_) (void)hipFree(b.second);
+  }
+  void* take(size_t bytes)
+  {
+    bytes = bytes ? bytes : 1;
+    size_t best = free_.size();
+    for (size_t i = 0; i < free_.size(); ++i)
+      if (free_[i].first >= bytes && (best == free_.size() || free_[i].first < free_[best].first)) best = i;
+    if (best != free_.size() && free_[best].first <= 2 * bytes + 4096) {
+      void* p = free_[best].second;
+      free_.erase(free_.begin() + (long)best);
+      return p;
+    }
+    void* p = nullptr;
+    HIP_OK(hipSetDevice(device_));
+    HIP_OK(hipMalloc(&p, bytes));
+    all_.emplace_back(bytes, p);
+    return p;
+  }
+  void give(void* p)
+  {
+    for (const auto& b : all_)
+      if (b.second == p) {
+        free_.push_back(b);
+        return;
+      }
+  }
+
+ private:
+  int device_;
+  std::vector<std::pair<size_t, void*>> all_, free_;
+};
+
 class RcclComm : public Comm {
  public:
-  RcclComm(ncclComm_t comm, int rank, int world, int device) : comm_(comm), rank_(rank), world_(world), device_(device)
+  RcclComm(ncclComm_t comm, int rank, int world, int device)
+      : comm_(comm), rank_(rank), world_(world), device_(device), pool_(device)
   {
     HIP_OK(hipSetDevice(device_));
     HIP_OK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
@@ -34,18 +79,24 @@ class RcclComm : public Comm {
   int rank() const override { return rank_; }
   int world() const override { return world_; }
   int on_device() const override { return 1; }
-  void* alloc(size_t bytes) override
-  {
-    void* p = nullptr;
-    HIP_OK(hipSetDevice(device_));
-    HIP_OK(hipMalloc(&p, bytes ? bytes : 1));
-    return p;
-  }
-  void release(void* p) override { (void)hipSetDevice(device_); (void)hipFree(p); }
+  void* alloc(size_t bytes) override { return pool_.take(bytes); }
+  void release(void* p) override { pool_.give(p); }
   void put(void* d, const void* s, size_t b) override { if (b) HIP_OK(hipMemcpy(d, s, b, hipMemcpyHostToDevice)); }
   void get(void* d, const void* s, size_t b) override { if (b) HIP_OK(hipMemcpy(d, s, b, hipMemcpyDeviceToHost)); }
-  void copy(void* d, const void* s, size_t b) override { if (b) HIP_OK(hipMemcpy(d, s, b, hipMemcpyDeviceToDevice)); }
-  void fill_ff(void* d, size_t b) override { if (b) { HIP_OK(hipMemset(d, 0xff, b)); HIP_OK(hipDeviceSynchronize()); } }
+  // device to device, and a fill: on the backend's own stream and complete on return (the library's stream and this
+  // one are non-blocking streams, which the null stream does not order)
+  void copy(void* d, const void* s, size_t b) override
+  {
+    if (!b) return;
+    HIP_OK(hipMemcpyAsync(d, s, b, hipMemcpyDeviceToDevice, stream_));
+    HIP_OK(hipStreamSynchronize(stream_));
+  }
+  void fill_ff(void* d, size_t b) override
+  {
+    if (!b) return;
+    HIP_OK(hipMemsetAsync(d, 0xff, b, stream_));
+    HIP_OK(hipStreamSynchronize(stream_));
+  }
   void all_reduce_max_f32(float* buf, size_t n) override
   {
     NCCL_OK(ncclAllReduce(buf, buf, n, ncclFloat, ncclMax, comm_, stream_));
@@ -87,26 +138,26 @@ class RcclComm : public Comm {
   ncclComm_t comm_;
   int rank_, world_, device_;
   hipStream_t stream_ = nullptr;
+  DevicePool pool_;
 };
 
 // threads + device buffers on one GPU: ThreadComm's rendezvous, hipMemcpy as the transport
 class DeviceThreadComm : public Comm {
  public:
-  DeviceThreadComm(ThreadGroup& g, int rank) : g_(g), rank_(rank) {}
+  DeviceThreadComm(ThreadGroup& g, int rank) : g_(g), rank_(rank), pool_(0) {}
   int rank() const override { return rank_; }
   int world() const override { return g_.world(); }
   int on_device() const override { return 1; }
-  void* alloc(size_t bytes) override
-  {
-    void* p = nullptr;
-    HIP_OK(hipSetDevice(0));
-    HIP_OK(hipMalloc(&p, bytes ? bytes : 1));
-    return p;
-  }
-  void release(void* p) override { (void)hipFree(p); }
+  void* alloc(size_t bytes) override { return pool_.take(bytes); }
+  void release(void* p) override { pool_.give(p); }
   void put(void* d, const void* s, size_t b) override { if (b) HIP_OK(hipMemcpy(d, s, b, hipMemcpyHostToDevice)); }
   void get(void* d, const void* s, size_t b) override { if (b) HIP_OK(hipMemcpy(d, s, b, hipMemcpyDeviceToHost)); }
-  void copy(void* d, const void* s, size_t b) override { if (b) HIP_OK(hipMemcpy(d, s, b, hipMemcpyDeviceToDevice)); }
+  void copy(void* d, const void* s, size_t b) override
+  {
+    if (!b) return;
+    HIP_OK(hipMemcpy(d, s, b, hipMemcpyDeviceToDevice));
+    HIP_OK(hipDeviceSynchronize());  // (complete on return, whichever stream reads it next)
+  }
   void fill_ff(void* d, size_t b) override { if (b) { HIP_OK(hipMemset(d, 0xff, b)); HIP_OK(hipDeviceSynchronize()); } }
   void all_reduce_max_f32(float* buf, size_t n) override
   {
@@ -166,6 +217,7 @@ class DeviceThreadComm : public Comm {
   }
   ThreadGroup& g_;
   int rank_;
+  DevicePool pool_;
 };
 
 }  // namespace
@@ -200,7 +252,8 @@ int run_cloud_as_ranks_on_gpu0(int n_ranks, const hope_config& cfg, const float*
         const size_t lo = n * (size_t)r / (size_t)n_ranks, hi = n * (size_t)(r + 1) / (size_t)n_ranks;
         status[r] = segment_cloud_multi(ctxs[r], comm, xyz_host + 3 * lo, hi - lo, apply, cfg, results[r], errs[r]);
       } catch (const std::exception& e) {
-        status[r] = HOPE_E_INVALID;
+        group.abort();  // (the other ranks' next rendezvous throws instead of waiting for this one)
+        status[r] = HOPE_E_HIP;
         errs[r] = e.what();
       }
     });
@@ -235,6 +288,8 @@ int run_cloud_on_gpus(int n_gpus, const hope_config& cfg, const float* xyz_host,
   std::vector<std::string> errs((size_t)n_gpus);
   std::vector<MultiResult> results((size_t)n_gpus);
   std::vector<std::thread> threads;
+  std::once_flag abort_once;
+  std::atomic<bool> aborted(false);
   for (int r = 0; r < n_gpus; ++r)
     threads.emplace_back([&, r] {
       hope_ctx* ctx = nullptr;
@@ -247,15 +302,21 @@ int run_cloud_on_gpus(int n_gpus, const hope_config& cfg, const float* xyz_host,
         const size_t lo = n * (size_t)r / (size_t)n_gpus, hi = n * (size_t)(r + 1) / (size_t)n_gpus;
         status[r] = segment_cloud_multi(ctx, comm, xyz_host + 3 * lo, hi - lo, apply, c, results[r], errs[r]);
       } catch (const std::exception& e) {
-        // (a rank that fails before a collective leaves the others waiting in it: RCCL has no timeout here, so the
-        //  errors that can be foreseen -- arguments, device count -- are checked before the threads start)
-        status[r] = HOPE_E_INVALID;
+        // a HIP / RCCL error on this rank (a library step that fails is agreed on inside segment_cloud_multi): the
+        // other ranks may be waiting for it inside a collective, and RCCL has no timeout -- abort every communicator
+        // once, which makes their pending operations fail and their threads come back
+        status[r] = HOPE_E_HIP;
         errs[r] = e.what();
+        std::call_once(abort_once, [&] {
+          aborted = true;
+          for (int k = 0; k < n_gpus; ++k) ncclCommAbort(comms[k]);
+        });
       }
       if (ctx) hope_destroy(ctx);
     });
   for (std::thread& t : threads) t.join();
-  for (int r = 0; r < n_gpus; ++r) ncclCommDestroy(comms[r]);
+  if (!aborted)
+    for (int r = 0; r < n_gpus; ++r) ncclCommDestroy(comms[r]);
   for (int r = 0; r < n_gpus; ++r)
     if (status[r] < 0) {
       err = "rank " + std::to_string(r) + ": " + errs[r];

@@ -151,6 +151,30 @@ def _all_gather_rows(mine, sizes, dist):
     return torch.cat([p[:s] for p, s in zip(parts, sizes)]).contiguous()
 
 
+HOST_SYNCS = 0          # exchanges whose result the host waited for, in the last call of segment_cloud_sharded
+_HIST_CAP = 8192        # z layers a rank's histogram may span in the fused first exchange
+
+
+def _exchange(values, dist, dev):
+    """All-gather of a short int64 vector per rank -> numpy [world, len(values)].  The ONE place where the host waits
+    for a collective: sizes shape the next allocation or the next collective's counts, so they have to come back."""
+    import torch
+    global HOST_SYNCS
+    mine = torch.as_tensor(np.asarray(values, dtype=np.int64), device=dev)
+    parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    HOST_SYNCS += 1
+    return torch.stack(parts).cpu().numpy()
+
+
+def _f32_bits(a):
+    return np.asarray(a, dtype=np.float32).view(np.uint32).astype(np.int64)
+
+
+def _bits_f32(a):
+    return np.asarray(a, dtype=np.int64).astype(np.uint32).view(np.float32)
+
+
 def segment_cloud_sharded(ctx, xyz_local, dist, apply_filter_transform=False, allow_bands=True):
     """xyz_local: this rank's contiguous share of the cloud, float32 torch tensor [n, 3] (CPU with
     gloo, cuda with nccl = RCCL).  Ranks hold the points in rank order (rank 0 the lowest indices).
@@ -162,72 +186,89 @@ def segment_cloud_sharded(ctx, xyz_local, dist, apply_filter_transform=False, al
     as if one process had called segment_cloud.  info["result"] = merge_band_results' dictionary (clusters in the
     reference's order, labels of all fit points, n_segments, n_clusters, n_planes); A1..A8 accessors of `ctx` are
     those of the whole cloud on both paths.
+
+    The host waits for five exchanges (HOST_SYNCS; info["host_syncs"]), each a short vector of sizes per rank that the
+    next step cannot be shaped without: (1) survivors + bounding box + the rank's OWN z-layer histogram (binned on
+    its own box: layers are floor(z / th_z), the same on every rank, so the histograms add up after a shift -- the
+    global box and the global histogram come out of one exchange), (2) the routed counts of the all-to-all, (3) the
+    sizes of the down-sampled pieces, (4) the fit points per band + the band-crossing check, (5) the clusters per
+    band.  Payloads never touch the host.
     Returns a dict of the exchanged sizes, the path taken and the result."""
     import torch
+    global HOST_SYNCS
+    HOST_SYNCS = 0
     world, rank = dist.get_world_size(), dist.get_rank()
     xyz_local = xyz_local.contiguous()
     dev = xyz_local.device
     n = xyz_local.shape[0]
     ptr, on_dev = _ptr(xyz_local)
     _sync(xyz_local)
-    # 1. bounding box (MIN/MAX as one MAX over [-min, max]) and survivor count
+    # 1. survivors, bounding box and z-layer histogram in ONE exchange: every rank bins its points on its own box
     bbox, n_raw = ctx.shard_bbox(ptr, n, 12, apply_filter_transform, on_dev)
-    mm = torch.tensor(np.concatenate([-bbox[:3], bbox[3:]]), dtype=torch.float32, device=dev)
-    cnt = torch.tensor([n_raw], dtype=torch.int64, device=dev)
-    dist.all_reduce(mm, op=dist.ReduceOp.MAX)
-    dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-    n_raw_total = int(cnt.item())
-    mmh = mm.cpu().numpy()
-    gbbox = np.concatenate([-mmh[:3], mmh[3:]]).astype(np.float32)
+    own_min_bz, own_bins, own_hist = 0, 0, np.zeros(0, np.int64)
+    if n_raw > 0:
+        mn, dv, _ = ctx.grid_from_bbox(bbox)
+        own_min_bz, own_bins = int(mn[2]), int(dv[2])
+        if own_bins <= _HIST_CAP:
+            own_hist = ctx.shard_z_histogram(ptr, n, 12, apply_filter_transform, on_dev, bbox, own_bins)
+    fused = own_bins <= _HIST_CAP
+    head = np.concatenate([[n_raw, own_min_bz, own_bins if fused else -1], _f32_bits(bbox)])
+    body = np.zeros(_HIST_CAP, np.int64)
+    body[:own_hist.shape[0]] = own_hist
+    got = _exchange(np.concatenate([head, body]), dist, dev)
+    n_raw_total = int(got[:, 0].sum())
     if n_raw_total == 0:
         ctx.segment_cloud(np.zeros((0, 3), np.float32))
         return {"n_raw_total": 0, "n_vox": 0, "sent": [0] * world, "received": [0] * world, "path": "empty",
-                "result": whole_result(ctx)}
-    _, div_b, st = ctx.grid_from_bbox(gbbox)
+                "result": whole_result(ctx), "host_syncs": HOST_SYNCS}
+    live = got[:, 0] > 0
+    boxes = np.stack([_bits_f32(got[r, 3:9]) for r in range(world)])
+    gbbox = np.concatenate([boxes[live, :3].min(0), boxes[live, 3:].max(0)]).astype(np.float32)
+    gmin_b, div_b, st = ctx.grid_from_bbox(gbbox)
     n_bins = int(div_b[2])
-    # 2. z-layer histogram -> bands
-    hist = torch.from_numpy(ctx.shard_z_histogram(ptr, n, 12, apply_filter_transform, on_dev, gbbox, n_bins)).to(dev)
-    dist.all_reduce(hist, op=dist.ReduceOp.SUM)
-    owner = band_partition(hist.cpu().numpy(), world)
-    # 3. route the survivors to their band owners
+    if (got[live, 2] >= 0).all():
+        hist = np.zeros(n_bins, np.int64)
+        for r in np.nonzero(live)[0]:
+            off, nb = int(got[r, 1]) - int(gmin_b[2]), int(got[r, 2])
+            hist[off:off + nb] += got[r, 9:9 + nb]
+    else:
+        # a rank whose own box spans more layers than the fused exchange carries: the histogram on the global box,
+        # summed by an all-reduce of its own (one more wait)
+        h = torch.from_numpy(ctx.shard_z_histogram(ptr, n, 12, apply_filter_transform, on_dev, gbbox, n_bins)).to(dev)
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        HOST_SYNCS += 1
+        hist = h.cpu().numpy()
+    owner = band_partition(hist, world)
+    # 2. route the survivors to their band owners
     routed = torch.empty((max(n_raw, 1), 3), dtype=torch.float32, device=dev)
     counts = ctx.shard_route(ptr, n, 12, apply_filter_transform, on_dev, gbbox, owner, world, routed.data_ptr(),
                              routed.is_cuda)
-    send = torch.tensor(counts, dtype=torch.int64, device=dev)
-    recv = torch.empty(world, dtype=torch.int64, device=dev)
-    dist.all_to_all_single(recv, send)
-    recv_l, send_l = [int(v) for v in recv.cpu().tolist()], [int(v) for v in counts]
+    sent_by = _exchange(counts, dist, dev)                      # [source, destination]
+    send_l, recv_l = [int(v) for v in counts], [int(v) for v in sent_by[:, rank]]
     mine = torch.empty((max(sum(recv_l), 1), 3), dtype=torch.float32, device=dev)
+    _sync(routed)
     dist.all_to_all_single(mine[:sum(recv_l)].view(-1), routed[:n_raw].view(-1), [3 * v for v in recv_l],
                            [3 * v for v in send_l])
-    # 4. VoxelGrid on the band with the global grid; gather the down-sampled cloud
+    # 3. VoxelGrid on the band with the global grid; gather the down-sampled cloud
     _sync(mine)
     ctx.downsample_cloud_bbox(mine.data_ptr(), sum(recv_l), 12, mine.is_cuda, gbbox)
     vox_local = torch.empty((int(ctx.counts(0).n_vox), 3), dtype=torch.float32, device=dev)
     if vox_local.shape[0]:
         ctx.downsampled_to(vox_local.data_ptr(), vox_local.is_cuda)
-    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
-    sizes[rank] = vox_local.shape[0]
-    dist.all_reduce(sizes, op=dist.ReduceOp.SUM)
-    sizes_l = [int(v) for v in sizes.cpu().tolist()]
-    pad = max(max(sizes_l), 1)
-    buf = torch.zeros((pad, 3), dtype=torch.float32, device=dev)
-    buf[:vox_local.shape[0]] = vox_local
-    parts = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(parts, buf)
-    vox_all = torch.cat([p[:s] for p, s in zip(parts, sizes_l)]).contiguous()
-    # 5. A6..A12 on the whole down-sampled cloud; the two neighbour searches (A6, A8) are shared by z band:
+    sizes_l = [int(v) for v in _exchange([vox_local.shape[0]], dist, dev)[:, 0]]
+    vox_all = _all_gather_rows(vox_local, sizes_l, dist)
+    # 4. A6..A12 on the whole down-sampled cloud; the two neighbour searches (A6, A8) are shared by z band:
     #    every rank holds all points, so its own band (a contiguous index range) needs no halo
     n_vox = int(vox_all.shape[0])
     _sync(vox_all)
     if n_vox == 0:
         ctx.segment_cloud(np.zeros((0, 3), np.float32))
         return {"n_raw_total": n_raw_total, "n_vox": 0, "sent": send_l, "received": recv_l, "bands": owner,
-                "path": "empty", "result": whole_result(ctx)}
+                "path": "empty", "result": whole_result(ctx), "host_syncs": HOST_SYNCS}
     if world == 1:
         ctx.segment_downsampled(vox_all.data_ptr(), n_vox, 12, vox_all.is_cuda, gbbox, n_raw_total)
         return {"n_raw_total": n_raw_total, "n_vox": n_vox, "sent": send_l, "received": recv_l, "bands": owner,
-                "path": "one rank", "result": whole_result(ctx)}
+                "path": "one rank", "result": whole_result(ctx), "host_syncs": HOST_SYNCS}
     first, count = sum(sizes_l[:rank]), sizes_l[rank]
     args = (vox_all.data_ptr(), n_vox, 12, vox_all.is_cuda, gbbox, n_raw_total, first, count)
     ctx.segment_downsampled_staged(*args, stop_after=1)
@@ -238,27 +279,24 @@ def segment_cloud_sharded(ctx, xyz_local, dist, apply_filter_transform=False, al
     ctx.segment_downsampled_staged(*args, normals_ptr=normals_all.data_ptr(), stop_after=2)
     fit_idx = ctx.fit_indices(0)
     lo, hi = (int(v) for v in np.searchsorted(fit_idx, [first, first + count]))
-    fit_sizes = torch.zeros(world, dtype=torch.int64, device=dev)
-    fit_sizes[rank] = hi - lo
-    dist.all_reduce(fit_sizes, op=dist.ReduceOp.SUM)
-    fit_sizes_l = [int(v) for v in fit_sizes.cpu().tolist()]
-    n_fit = sum(fit_sizes_l)
-    base = {"n_raw_total": n_raw_total, "n_vox": n_vox, "n_fit": n_fit, "sent": send_l, "received": recv_l,
-            "bands": owner, "own_vox": sizes_l, "own_fit": fit_sizes_l}
     K = ctx.cfg.knn
     own_k = torch.empty((hi - lo, K), dtype=torch.int32, device=dev)
     if hi > lo:
         ctx.knn_rows(lo, hi - lo, out_ptr=own_k.data_ptr(), out_on_device=own_k.is_cuda)
-    # 6. A9..A12 by z band when the bands are independent: no valid edge (|dz| < th_z, validatePoint
+    # 5. A9..A12 by z band when the bands are independent: no valid edge (|dz| < th_z, validatePoint
     #    z_growing.cpp:335-364) leaves a band.  True by construction when the cuts sit at empty layers; checked
     #    on the k-NN rows themselves (every rank its own rows: an edge into a band is an edge out of another).
-    crossing = torch.zeros(1, dtype=torch.int32, device=dev)
-    if hi > lo and allow_bands:
-        crossing[0] = int(ctx.count_band_crossings(lo, hi - lo) > 0)
-    if not allow_bands:
-        crossing[0] = 1
-    dist.all_reduce(crossing, op=dist.ReduceOp.MAX)
-    if int(crossing.item()) == 0:
+    #    The size filter is what drops the other bands' points (rows without neighbours: singletons), so a minimum
+    #    cluster size of 1 takes the replicated path.
+    crossing = 0 if (allow_bands and ctx.cfg.min_cluster > 1) else 1
+    if crossing == 0 and hi > lo:
+        crossing = int(ctx.count_band_crossings(lo, hi - lo) > 0)
+    got = _exchange([hi - lo, crossing], dist, dev)
+    fit_sizes_l = [int(v) for v in got[:, 0]]
+    n_fit = sum(fit_sizes_l)
+    base = {"n_raw_total": n_raw_total, "n_vox": n_vox, "n_fit": n_fit, "sent": send_l, "received": recv_l,
+            "bands": owner, "own_vox": sizes_l, "own_fit": fit_sizes_l}
+    if int(got[:, 1].sum()) == 0:
         # every band is closed under the neighbour relation: regions grow, and clusters are verified, inside the
         # own band only; the points of other bands come as rows without neighbours (singletons, dropped by the
         # size filter).  Seed ranks are those of the whole fit cloud, so rank 0 merges by seed rank.
@@ -267,18 +305,27 @@ def segment_cloud_sharded(ctx, xyz_local, dist, apply_filter_transform=False, al
         _sync(knn_part)
         ctx.segment_downsampled_staged(*args, normals_ptr=normals_all.data_ptr(), knn_ptr=knn_part.data_ptr(), stop_after=0)
         c = ctx.counts(0)
-        cl = ctx.clusters(0).copy()
-        lab = ctx.labels(0)[lo:hi].copy()
-        seg_own = int(c.n_segments) - (n_fit - (hi - lo)) if ctx.cfg.min_cluster > 1 else int(c.n_segments)
-        mine_part = (lo, hi, cl, lab, seg_own)
+        cl = np.ascontiguousarray(ctx.clusters(0))
+        lab = np.ascontiguousarray(ctx.labels(0)[lo:hi], dtype=np.int32)
+        seg_own = int(c.n_segments) - (n_fit - (hi - lo))
+        meta = _exchange([len(cl), seg_own], dist, dev)
+        # the records and the own labels as fixed-layout rows (no pickling)
+        rec_bytes = cl.dtype.itemsize
+        cl_t = torch.from_numpy(cl.view(np.uint8).reshape(len(cl), rec_bytes).copy()).to(dev)
+        cl_all = _all_gather_rows(cl_t, [int(v) for v in meta[:, 0]], dist)
+        lab_all = _all_gather_rows(torch.from_numpy(lab.reshape(-1, 1).copy()).to(dev), fit_sizes_l, dist)
+        merged = None
         if rank == 0:
-            parts = [None] * world
-            dist.gather_object(mine_part, parts, dst=0)
+            from hope_amd.capi import CLUSTER_DTYPE
+            recs = cl_all.cpu().numpy().reshape(-1).view(CLUSTER_DTYPE)
+            labs = lab_all.cpu().numpy().reshape(-1)
+            parts, c0, f0 = [], 0, 0
+            for r in range(world):
+                ncl, nf = int(meta[r, 0]), fit_sizes_l[r]
+                parts.append((f0, f0 + nf, recs[c0:c0 + ncl], labs[f0:f0 + nf], int(meta[r, 1])))
+                c0, f0 = c0 + ncl, f0 + nf
             merged = merge_band_results(parts, n_fit)
-        else:
-            dist.gather_object(mine_part, None, dst=0)
-            merged = None
-        base.update({"path": "z-bands", "result": merged})
+        base.update({"path": "z-bands", "result": merged, "host_syncs": HOST_SYNCS})
         return base
     # fallback: edges cross the band cuts (no empty layer to cut at): all-gather the k-NN rows and run A9..A12
     # on the whole fit cloud on every rank
@@ -288,5 +335,5 @@ def segment_cloud_sharded(ctx, xyz_local, dist, apply_filter_transform=False, al
         knn_all = _all_gather_rows(own_k, fit_sizes_l, dist)
     _sync(knn_all)
     ctx.segment_downsampled_staged(*args, normals_ptr=normals_all.data_ptr(), knn_ptr=knn_all.data_ptr(), stop_after=0)
-    base.update({"path": "replicated", "result": whole_result(ctx)})
+    base.update({"path": "replicated", "result": whole_result(ctx), "host_syncs": HOST_SYNCS})
     return base

@@ -51,7 +51,8 @@ enum {
   HOPE_E_INVALID = -1,      /* bad argument */
   HOPE_E_HIP = -2,          /* HIP runtime error */
   HOPE_E_NOMEM = -3,
-  HOPE_E_RANGE = -4         /* a frame index / capacity is out of range */
+  HOPE_E_RANGE = -4,        /* a frame index / capacity is out of range */
+  HOPE_E_PEER = -5          /* a collective multi-rank call: another rank failed (hope_amd/host/multi_gpu.hpp) */
 };
 
 /* Which class's post-clustering semantics to apply. */

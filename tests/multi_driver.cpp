@@ -1,8 +1,11 @@
 // Test driver: segment_cloud_multi (hope_amd/host/multi_gpu.cpp) on N threads over ThreadComm, every rank with a ctx of
 // the library this file is linked against (tests/Makefile: the CPU oracle).  usage: multi_driver <cloud.f32> <ranks>
-// <apply 0|1> <allow_bands 0|1>; prints one JSON line with rank 0's merged result.
+// <apply 0|1> <allow_bands 0|1> [fail_rank fail_step [throw 0|1]]; prints one JSON line with rank 0's merged result.
+// With a fault injected (a library step of one rank fails, or that rank throws): every rank must come back, the exit
+// code is 3 and stderr names each rank's status.
 #include <cstdio>
 #include <fstream>
+#include <stdexcept>
 #include <thread>
 #include <vector>
 
@@ -10,7 +13,9 @@
 
 int main(int argc, char** argv)
 {
-  if (argc != 5) { std::fprintf(stderr, "usage: multi_driver <cloud.f32> <ranks> <apply> <allow_bands>\n"); return 2; }
+  if (argc != 5 && argc != 7 && argc != 8) { std::fprintf(stderr, "usage: multi_driver <cloud.f32> <ranks> <apply> <allow_bands> [fail_rank fail_step [throw]]\n"); return 2; }
+  const int fail_rank = argc >= 7 ? std::atoi(argv[5]) : -1, fail_step = argc >= 7 ? std::atoi(argv[6]) : -1;
+  const bool do_throw = argc == 8 && std::atoi(argv[7]) != 0;
   std::ifstream in(argv[1], std::ios::binary);
   std::vector<char> raw((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
   const size_t n = raw.size() / 12;
@@ -30,12 +35,22 @@ int main(int argc, char** argv)
       if (hope_create(&cfg, &ctx) != HOPE_OK) { status[r] = -100; return; }
       hope::ThreadComm comm(group, r);
       const size_t lo = n * (size_t)r / (size_t)world, hi = n * (size_t)(r + 1) / (size_t)world;
-      status[r] = hope::segment_cloud_multi(ctx, comm, xyz + 3 * lo, hi - lo, apply, cfg, res[r], errs[r], allow);
+      try {
+        if (do_throw && r == fail_rank) throw std::runtime_error("injected exception");
+        status[r] = hope::segment_cloud_multi(ctx, comm, xyz + 3 * lo, hi - lo, apply, cfg, res[r], errs[r], allow,
+                                              do_throw ? -1 : fail_rank, fail_step);
+      } catch (const std::exception& e) {
+        group.abort();  // nobody waits for this rank any more
+        status[r] = -101;
+        errs[r] = e.what();
+      }
       hope_destroy(ctx);
     });
   for (std::thread& t : th) t.join();
+  bool failed = false;
   for (int r = 0; r < world; ++r)
-    if (status[r] < 0) { std::fprintf(stderr, "rank %d: %d %s\n", r, status[r], errs[r].c_str()); return 1; }
+    if (status[r] < 0) { std::fprintf(stderr, "rank %d: %d %s\n", r, status[r], errs[r].c_str()); failed = true; }
+  if (failed) return fail_rank >= 0 ? 3 : 1;
   const hope::MultiResult& m = res[0];
   std::printf("{\"path\": \"%s\", \"status\": %d, \"n_raw\": %lld, \"n_vox\": %lld, \"n_fit\": %lld, \"n_segments\": %d, \"n_planes\": %d, "
               "\"received\": [", m.path.c_str(), status[0], (long long)m.n_raw_total, (long long)m.n_vox, (long long)m.n_fit,

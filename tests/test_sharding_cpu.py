@@ -90,7 +90,7 @@ def _ramp_cloud():
     return np.concatenate([xy, z[:, None]], 1).astype(np.float32)
 
 
-def _cloud_worker(rank, world, port, q, apply, layered=False, allow_bands=True):
+def _cloud_worker(rank, world, port, q, apply, layered=False, allow_bands=True, min_cluster=3):
     import torch
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -104,7 +104,7 @@ def _cloud_worker(rank, world, port, q, apply, layered=False, allow_bands=True):
     if apply:
         xyz = xyz * np.float32(0.25) + np.array([0, 0, 0.2], np.float32)
     lo, hi = frame_partition(xyz.shape[0], world, rank)
-    ctx = HopeContext(HopeLib(ORACLE_LIB, "hope_oracle_"))
+    ctx = HopeContext(HopeLib(ORACLE_LIB, "hope_oracle_"), min_cluster=min_cluster)
     if apply:
         ctx.set_pose(np.array([0.1, -0.2, 0.3], np.float32), np.array([0.02, -0.01, 0.38, 0.92], np.float32))
     info = segment_cloud_sharded(ctx, torch.from_numpy(xyz[lo:hi].copy()), dist, apply_filter_transform=apply,
@@ -115,7 +115,7 @@ def _cloud_worker(rank, world, port, q, apply, layered=False, allow_bands=True):
         res = {"clusters": np.asarray(res["clusters"]).tobytes(), "labels": np.asarray(res["labels"]).tobytes(),
                "n_segments": res["n_segments"], "n_clusters": res["n_clusters"], "n_planes": res["n_planes"]}
     q.put((rank, summary(ctx, 0), info["sent"], info["received"], info["path"], res,
-           [int(v) for v in info.get("own_fit", [])]))
+           [int(v) for v in info.get("own_fit", [])], info["host_syncs"]))
     dist.destroy_process_group()
 
 
@@ -123,7 +123,7 @@ def _run_ranks(world, port, **kw):
     mpctx = mp.get_context("spawn")
     q = mpctx.Queue()
     procs = [mpctx.Process(target=_cloud_worker, args=(r, world, port, q, kw.get("apply", False), kw.get("layered", False),
-                                                       kw.get("allow_bands", True))) for r in range(world)]
+                                                       kw.get("allow_bands", True), kw.get("min_cluster", 3))) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=240) for _ in range(world)]
@@ -133,9 +133,9 @@ def _run_ranks(world, port, **kw):
     return sorted(got, key=lambda g: g[0])
 
 
-def _single_result(oracle_lib, xyz):
+def _single_result(oracle_lib, xyz, **cfg):
     from hope_amd.capi import HopeContext
-    ctx = HopeContext(oracle_lib)
+    ctx = HopeContext(oracle_lib, **cfg)
     ctx.segment_cloud(xyz)
     c = ctx.counts(0)
     cl = ctx.clusters(0)
@@ -157,8 +157,18 @@ def test_clustering_partitioned_by_z_band(oracle_lib):
         assert [g[4] for g in got] == ["z-bands"] * world
         assert got[0][5] == single and all(g[5] is None for g in got[1:])
         assert sum(1 for v in got[0][6] if v > 0) >= 2          # at least two ranks really own fit points
+        # the host waits for five exchanges of sizes (box + histogram fused, routed counts, down-sampled sizes,
+        # fit sizes + crossing check, clusters per band); payloads never come back to it
+        assert all(g[7] == 5 for g in got)
     got = _run_ranks(2, 32600 + (os.getpid() % 2000), layered=True, allow_bands=False)
     assert [g[4] for g in got] == ["replicated"] * 2 and all(g[5] == single for g in got)
+    assert all(g[7] == 4 for g in got)
+    # the band path relies on the size filter dropping the other bands' points (singletons): a minimum cluster size
+    # of 1 keeps them, so that setting takes the replicated path
+    single1 = _single_result(oracle_lib, xyz, min_cluster=1)
+    assert single1["n_clusters"] > single["n_clusters"]
+    got = _run_ranks(2, 32650 + (os.getpid() % 2000), layered=True, min_cluster=1)
+    assert [g[4] for g in got] == ["replicated"] * 2 and all(g[5] == single1 for g in got)
 
 
 def test_bands_without_empty_layers_fall_back(oracle_lib):
@@ -211,7 +221,7 @@ def test_one_cloud_on_two_ranks_matches_one_process(oracle_lib):
         for p in procs:
             p.join(timeout=60)
             assert p.exitcode == 0
-        for rank, summ, sent, received, path, res, own_fit in got:
+        for rank, summ, sent, received, path, res, own_fit, _syncs in got:
             assert sum(sent) > 0 and min(received) > 0       # both bands are populated: points really moved
             for k in ("n_raw", "n_vox", "n_fit", "grid", "min_b", "sha_downsampled", "sha_normals", "sha_fit_indices"):
                 assert summ[k] == single[k], (rank, k)        # A1..A8 of the whole cloud on every rank
