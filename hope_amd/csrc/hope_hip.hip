@@ -48,6 +48,7 @@ namespace {
 constexpr int kMaxDevices = 64;
 StaticScratch* g_scratch_ptr[kMaxDevices] = {};  // per device; written under g_scratch_mutex
 std::mutex g_scratch_mutex;
+std::mutex g_scratch_use[kMaxDevices];           // held across a call that uses a device's array
 
 struct Pose {
   float t[3];
@@ -675,7 +676,7 @@ int stage_voxel_part(hope_ctx* c, const Src& src, size_t N, int cell_bits, float
   hipLaunchKernelGGL(k_part_finish_small, dim3(nblk(n_buckets, kFinWaves)), dim3(kFinThreads), 0, s,
                      (const float4*)buf[cur], (const uint32_t*)bstart, n_buckets, tmp, vox_cnt, big, big_n);
   hipLaunchKernelGGL(k_part_finish_big, dim3(kFinGrid), dim3(kFinThreads), 0, s, (const float4*)buf[cur],
-                     (const uint32_t*)bstart, (const uint32_t*)big, big_n, tmp, vox_cnt);
+                     (const uint32_t*)bstart, n_buckets, (const uint32_t*)big, big_n, tmp, vox_cnt);
   scan_exclusive_u32(vox_cnt, vox_cnt, (size_t)n_buckets + 1, sums, s);  // now: the buckets' first voxels
   hipLaunchKernelGGL(k_part_vox_total, dim3(1), dim3(1), 0, s, c->d_fi, (const uint32_t*)vox_cnt, n_buckets, c->d_glob);
   int st = sync_globals(c);
@@ -1553,12 +1554,13 @@ HOPE_API int hope_create(const hope_config* cfg, hope_ctx** out)
       void* p = nullptr;
       const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
       if (e != hipSuccess || !p) {
+        // only hope_shard_z_histogram_static needs it: that entry point reports the missing scratch, every other
+        // one works without
         std::fprintf(stderr, "hope_create: hipGetSymbolAddress(scratch) failed: %s\n", hipGetErrorString(e));
         (void)hipGetLastError();
-        hope_destroy(c);
-        return HOPE_E_HIP;
+      } else {
+        g_scratch_ptr[cfg->device] = static_cast<StaticScratch*>(p);
       }
-      g_scratch_ptr[cfg->device] = static_cast<StaticScratch*>(p);
     }
     c->d_scratch = cfg->device < kMaxDevices ? g_scratch_ptr[cfg->device] : nullptr;
   }
@@ -2001,6 +2003,7 @@ HOPE_API int hope_shard_z_histogram_static(hope_ctx* c, const void* xyz_dev, siz
     return HOPE_E_HIP;
   }
   HIPCHK(hipSetDevice(c->cfg.device));
+  std::lock_guard<std::mutex> in_use(g_scratch_use[c->cfg.device]);  // (one call at a time per GPU: the array is shared)
   StaticScratch* sp = c->d_scratch;  // (the device address: never the array's name)
   hipStream_t s = c->stream;
   CloudSrc src;

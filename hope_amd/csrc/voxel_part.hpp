@@ -36,9 +36,19 @@ constexpr int kPartChunk = 4 * kPartTile;          // 16384 records per workgrou
 constexpr int kFinThreads = 256;                   // workgroup of k_part_finish
 constexpr int kFinWaves = kFinThreads / kWave;
 constexpr int kFinTile = kFinThreads * 8;          // 2048 records
+constexpr int kFinLong = 16384;                    // records from which a bucket is started early
 constexpr int kFinGrid = 1024;                     // workgroups of k_part_finish_big (4 per CU)
 static_assert(kPartThreads == kPartDigits, "k_part_scatter scans one digit per thread");
 static_assert(kFinThreads * 2 == kPartCells, "k_part_finish keeps two cells per thread");
+
+// cell index of an (already filtered and transformed) point
+__device__ __forceinline__ unsigned part_cell_of(const FrameInfo& F, float inv_xy, float inv_z, float x, float y, float z)
+{
+  const int i0 = (int)(floorf(x * inv_xy) - (float)F.min_b[0]);
+  const int i1 = (int)(floorf(y * inv_xy) - (float)F.min_b[1]);
+  const int i2 = (int)(floorf(z * inv_z) - (float)F.min_b[2]);
+  return (unsigned)(i0 + i1 * F.div_b[0] + i2 * (F.div_b[0] * F.div_b[1]));
+}
 
 // cell index of input point i (A2/A3 applied), false if the point is dropped
 template <class Src>
@@ -46,11 +56,7 @@ __device__ __forceinline__ bool part_cell(const Src& src, const FrameInfo* fi, f
                                           float& x, float& y, float& z, unsigned& cell)
 {
   if (!load_point(src, fi, 0, i, x, y, z)) return false;
-  const FrameInfo& F = fi[0];
-  const int i0 = (int)(floorf(x * inv_xy) - (float)F.min_b[0]);
-  const int i1 = (int)(floorf(y * inv_xy) - (float)F.min_b[1]);
-  const int i2 = (int)(floorf(z * inv_z) - (float)F.min_b[2]);
-  cell = (unsigned)(i0 + i1 * F.div_b[0] + i2 * (F.div_b[0] * F.div_b[1]));
+  cell = part_cell_of(fi[0], inv_xy, inv_z, x, y, z);
   return true;
 }
 
@@ -219,7 +225,7 @@ k_part_bounds(const float4* rec, const FrameInfo* fi, unsigned n_buckets, uint32
 // records), vox_cnt[b] their number.
 //
 // k_part_finish_small: one wave per bucket.  Empty buckets and buckets of up to 64 records are finished here;
-// the others are appended to `big` (big_n[0] counts them; any order).
+// the others are listed in `big` (n_buckets entries; big_n[0] / big_n[2] count the front / back entries; any order).
 __global__ void __launch_bounds__(kFinThreads)
 k_part_finish_small(const float4* rec, const uint32_t* bstart, unsigned n_buckets, float4* out, uint32_t* vox_cnt,
                     uint32_t* big, uint32_t* big_n)
@@ -237,7 +243,12 @@ k_part_finish_small(const float4* rec, const uint32_t* bstart, unsigned n_bucket
     return;
   }
   if (hi - lo > (unsigned)kWave) {
-    if (lane == 0) big[atomicAdd(big_n, 1u)] = b;
+    // the longest buckets (shelf rows: 10^5 records) from the front of the list, the others from its back:
+    // k_part_finish_big starts at the front, so the long ones are under way while the short ones fill the gaps
+    if (lane == 0) {
+      if (hi - lo > (unsigned)kFinLong) big[atomicAdd(&big_n[0], 1u)] = b;
+      else big[n_buckets - 1u - atomicAdd(&big_n[2], 1u)] = b;
+    }
     return;
   }
   const bool ok = lo + (unsigned)lane < hi;
@@ -280,10 +291,11 @@ k_part_finish_small(const float4* rec, const uint32_t* bstart, unsigned n_bucket
 }
 
 // k_part_finish_big: the listed buckets, each by a whole workgroup; the workgroups of a fixed-size grid take the
-// next bucket of the list until it is used up (big_n[0] = length, big_n[1] = next entry, zero at launch).
+// next bucket of the list until it is used up (big_n[0] / big_n[2] = entries at the front / at the back of big[0 ..
+// n_buckets), big_n[1] = next entry, zero at launch).
 __global__ void __launch_bounds__(kFinThreads)
-k_part_finish_big(const float4* rec, const uint32_t* bstart, const uint32_t* big, uint32_t* big_n, float4* out,
-                  uint32_t* vox_cnt)
+k_part_finish_big(const float4* rec, const uint32_t* bstart, unsigned n_buckets, const uint32_t* big, uint32_t* big_n,
+                  float4* out, uint32_t* vox_cnt)
 {
   __shared__ float4 s_rec[kFinTile];
   __shared__ unsigned short s_cnt[kFinWaves][kPartCells];
@@ -294,14 +306,14 @@ k_part_finish_big(const float4* rec, const uint32_t* bstart, const uint32_t* big
   const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid / kWave;
   const unsigned long long lt = (1ull << lane) - 1ull;
   const unsigned cmask = (unsigned)kPartCells - 1u;
-  const unsigned n_big = big_n[0];
+  const unsigned n_long = big_n[0], n_big = n_long + big_n[2];
   for (;;) {
     __syncthreads();  // (s_next, s_scan: the readers of the previous round are done)
     if (tid == 0) s_next = atomicAdd(&big_n[1], 1u);
     __syncthreads();
     const unsigned at = s_next;
     if (at >= n_big) break;  // (the same for every thread; every workgroup gets here: the list is finite)
-    const unsigned b = big[at];
+    const unsigned b = at < n_long ? big[at] : big[n_buckets - 1u - (at - n_long)];
     const unsigned lo = bstart[b], hi = bstart[b + 1];
     // this thread's cells: tid and tid + 256 (a shelf row is a run of adjacent cells: one chain per lane)
     float ax[2] = {0.f, 0.f}, ay[2] = {0.f, 0.f}, az[2] = {0.f, 0.f};

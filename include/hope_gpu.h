@@ -243,14 +243,17 @@ HOPE_API int hope_shard_bbox(hope_ctx* ctx, const void* xyz, size_t n, size_t st
 HOPE_API int hope_shard_z_histogram(hope_ctx* ctx, const void* xyz, size_t n, size_t stride_bytes,
                                     int apply_filter_transform, int on_device,
                                     const float bbox_min_max[6], int64_t* hist, int n_bins);
-/* hope_shard_z_histogram for callers that cannot allocate (code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same result, bit for bit;
+/* hope_shard_z_histogram for callers that cannot allocate (tight serving loops, harnesses that forbid
+ * hipMalloc, code that must not disturb an allocator's state).  No counterpart in the reference.  It is a
+ * synchronous call (it ends with a stream synchronise, and with hist_on_device == 0 a copy to host memory),
+ * so it cannot itself run inside a stream capture.  Same result, bit for bit;
  * it calls no hipMalloc / hipFree / allocating routine: the cloud must already be in device memory, and the
  * scratch its kernels need (frame record, 64-bit bins merged from the workgroups' LDS-private votes) is a
  * static __device__ array of the library, 66 KiB on every GPU the library runs on, held until the process
  * ends.  Limit: n_bins <= 8192 z layers (HOPE_E_RANGE beyond).  hist: n_bins int64, host or
- * (hist_on_device != 0) device memory.  Every call on a GPU shares that GPU's array: calls that overlap
- * on one GPU (two ctxs, two threads) race -- serialise them. */
+ * (hist_on_device != 0) device memory.  Every call on a GPU shares that GPU's array; the library holds a
+ * per-GPU lock across the call, so calls from several ctxs or threads of ONE process take turns (the call
+ * blocks anyway); calls from different processes have their own copies of the array. */
 HOPE_API int hope_shard_z_histogram_static(hope_ctx* ctx, const void* xyz_device, size_t n,
                                            size_t stride_bytes, int apply_filter_transform,
                                            const float bbox_min_max[6], int64_t* hist, int n_bins,

@@ -34,7 +34,9 @@ def test_static_z_histogram_equals_the_allocating_one(hip_lib):
         assert st == 0 and 10 < n_bins <= 8192
         want = ctx.shard_z_histogram(dev.data_ptr(), n, 12, apply, True, bbox, n_bins)
         assert want.sum() == n_raw
+        free_before = torch.cuda.mem_get_info()[0]
         got_host = ctx.shard_z_histogram_static(dev.data_ptr(), n, 12, apply, bbox, n_bins)
+        assert torch.cuda.mem_get_info()[0] == free_before      # (hipMemGetInfo: the call took no device memory)
         out = torch.full((n_bins + 8,), -7, dtype=torch.int64, device="cuda")
         torch.cuda.synchronize()
         ctx.shard_z_histogram_static(dev.data_ptr(), n, 12, apply, bbox, n_bins, out_ptr=out.data_ptr())

@@ -127,10 +127,10 @@ int main(int argc, char** argv)
     hipLaunchKernelGGL(k_part_bounds, dim3((n_buckets + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, 0, (const float4*)buf[cur], fi, n_buckets, bstart);
     mark("bounds");
     hipMemsetAsync(vox_cnt + n_buckets, 0, 4, 0);
-    hipMemsetAsync(big_n, 0, 8, 0);
+    hipMemsetAsync(big_n, 0, 16, 0);
     hipLaunchKernelGGL(k_part_finish_small, dim3((n_buckets + kFinWaves - 1) / kFinWaves), dim3(kFinThreads), 0, 0, (const float4*)buf[cur], (const uint32_t*)bstart, n_buckets, buf[cur ^ 1], vox_cnt, big, big_n);
     mark("finish small");
-    hipLaunchKernelGGL(k_part_finish_big, dim3(kFinGrid), dim3(kFinThreads), 0, 0, (const float4*)buf[cur], (const uint32_t*)bstart, (const uint32_t*)big, big_n, buf[cur ^ 1], vox_cnt);
+    hipLaunchKernelGGL(k_part_finish_big, dim3(kFinGrid), dim3(kFinThreads), 0, 0, (const float4*)buf[cur], (const uint32_t*)bstart, n_buckets, (const uint32_t*)big, big_n, buf[cur ^ 1], vox_cnt);
     mark("finish big");
     scan_exclusive_u32(vox_cnt, vox_cnt, (size_t)n_buckets + 1, sums, 0);
     hipLaunchKernelGGL(k_part_vox_total, dim3(1), dim3(1), 0, 0, fi, (const uint32_t*)vox_cnt, n_buckets, glob);
