@@ -17,6 +17,8 @@ import sys
 from collections import defaultdict
 
 STAGE_OF = [  # kernel name fragment -> bench.py stage
+    ("k_part_count", "k_part_count"), ("k_part_scatter", "k_part_scatter"), ("k_part_", "k_part_finish"),
+    ("k_grid_", "k_column_table+gather"), ("k_xs_", "k_cluster_verify"), ("k_big_", "k_cluster_verify"),
     ("k_bbox", "k_bbox"), ("k_frame_grid", "k_frame_grid"), ("k_group_records", "k_voxel_keys"),
     ("k_group_keys", "k_voxel_keys"), ("k_fit_sorted", "fit_column_index"), ("k_fit_col_table", "fit_column_index"),
     ("k_voxel_rank", "k_voxel_rank"), ("k_frame_vox_scan", "k_voxel_rank"), ("k_voxel_keys", "k_voxel_keys"), ("k_centroids", "k_centroids"), ("k_column_keys", "k_column_keys"),
@@ -43,9 +45,11 @@ def load(d, counter):
 
 
 def main():
+    """pmc_traffic.py <fetch dir> <write dir> [steps] [output json name] [kernel filter: frames|cloud]"""
     fetch, calls = load(sys.argv[1], "FETCH_SIZE")
     write, _ = load(sys.argv[2], "WRITE_SIZE")
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    out_name = sys.argv[4] if len(sys.argv) > 4 else "hbm_traffic.json"
     rows = []
     for k in set(fetch) | set(write):
         if "hope::" not in k and "rocprim" not in k:
@@ -63,8 +67,19 @@ def main():
             if frag in k:
                 stage[st] += (2 * fetch.get(k, 0) + write.get(k, 0)) / steps
                 break
-    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "hbm_traffic.json")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, "profiles", out_name)
     json.dump({k: round(v) for k, v in stage.items()}, open(out, "w"), indent=1, sort_keys=True)
+    # where the figures come from: bench.py copies this next to roofline.traffic
+    import subprocess
+    try:
+        head = subprocess.check_output(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], text=True).strip()
+        dirty = bool(subprocess.check_output(["git", "-C", root, "status", "--porcelain", "--", "hope_amd", "bench.py"], text=True).strip())
+    except Exception:
+        head, dirty = os.environ.get("HOPE_PROFILED_HEAD", "unknown"), False
+    json.dump({"profiled_build": head + ("+uncommitted" if dirty else ""), "counters": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one "
+               "pass each; FETCH_SIZE doubled (gfx950)", "steps_profiled": steps},
+              open(out.replace(".json", ".meta.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
