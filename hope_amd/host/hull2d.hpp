@@ -37,8 +37,9 @@ inline int orient(double ax, double ay, double bx, double by, double cx, double 
 
 // indices (into `pts`) of the strict hull vertices of the xy projection, counter-clockwise from the
 // lexicographically smallest point; n < 3 distinct points gives what is there.
-template <class P>
-std::vector<int> hullIndicesXY(const std::vector<P>& pts, const std::vector<int>* subset = nullptr)
+// `Points`: any random-access container of points with x and y (std::vector<P>, or PCL's vector with Eigen's allocator).
+template <class Points>
+std::vector<int> hullIndicesXY(const Points& pts, const std::vector<int>* subset = nullptr)
 {
   std::vector<int> id;
   if (subset) id = *subset; else { id.resize(pts.size()); for (size_t i = 0; i < pts.size(); ++i) id[i] = (int)i; }
@@ -60,10 +61,11 @@ std::vector<int> hullIndicesXY(const std::vector<P>& pts, const std::vector<int>
 }
 
 // pcl::ConvexHull::reconstruct for a horizontal patch; returns the polygon area (qh totvol).
-template <class P>
-double computeHull(const Cloud<P>& cloud_2d, Cloud<P>& cloud_hull, std::vector<int>* hull_indices = nullptr,
+template <class CloudT>
+double computeHull(const CloudT& cloud_2d, CloudT& cloud_hull, std::vector<int>* hull_indices = nullptr,
                    const std::vector<int>* candidates = nullptr)
 {
+  typedef typename CloudT::PointType P;
   std::vector<int> h = hullIndicesXY(cloud_2d.points, candidates);
   double area2 = 0.0;
   for (size_t i = 0; i + 1 < h.size() && h.size() >= 3; ++i) {   // fan from h[0], ccw order -> positive
