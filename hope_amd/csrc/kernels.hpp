@@ -610,6 +610,41 @@ __device__ __forceinline__ unsigned chunk_groups(bool ok, float gx, float gy, fl
   return ng;
 }
 
+// The same groups from a cell code that every surviving lane already holds (k_bbox_records: the code relative to
+// the frame's camera cell): no fit test and no second compare path.  Lanes whose cell is outside the code range hold
+// garbage -- the caller raises Globals::code_overflow for them and the call is repeated in two passes.
+__device__ __forceinline__ unsigned chunk_groups_code(unsigned long long okm, unsigned code, unsigned long long& my_grp)
+{
+  unsigned long long todo = okm;
+  unsigned ng = 0;
+  int g_lo = 0, g_hi = 0;
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const unsigned k = (unsigned)__builtin_amdgcn_readlane((int)code, leader);
+    const unsigned long long grp = __builtin_amdgcn_ballot_w64(code == k) & okm;
+    writelane_u64(grp, leader, g_lo, g_hi);
+    todo &= ~grp;
+    ++ng;
+  }
+  my_grp = (unsigned long long)(unsigned)g_lo | ((unsigned long long)(unsigned)g_hi << 32);
+  return ng;
+}
+
+// fminf / fmaxf of values that are never NaN, without the canonicalising v_max(x, x) the compiler puts in front of
+// every operand it cannot prove quiet (the kernels here are bound by VALU issue)
+__device__ __forceinline__ float min_nn(float a, float b)
+{
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float max_nn(float a, float b)
+{
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // row / column of this lane's pixel of chunk c (cpb = chunks per band of rows); the divisions are
 // wave-uniform
 __device__ __forceinline__ void chunk_rowcol(unsigned c, int lane, unsigned cpb, int& row, int& col)
@@ -775,7 +810,8 @@ k_bbox_records(DepthSrc src, FrameInfo* fi, float inv_xy, float inv_z, unsigned 
 {
   const int frame = blockIdx.y;
   const int lane = threadIdx.x & (kWave - 1);
-  const unsigned wv = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+  // (the wave's number as a scalar: the chunk's row and column then come out of the scalar unit)
+  const unsigned wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave));
   const unsigned nwv = gridDim.x * (kBlock / kWave);
   float aff[12];
 #pragma unroll
@@ -785,7 +821,7 @@ k_bbox_records(DepthSrc src, FrameInfo* fi, float inv_xy, float inv_z, unsigned 
   const unsigned long long lt = (1ull << lane) - 1ull;
   float mn[3] = {INFINITY, INFINITY, INFINITY};
   float mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-  int cnt = 0;
+  int cnt = 0;  // (wave-uniform: survivors of the wave's chunks)
   bool over = false;
   for (unsigned c = wv; c < cpf; c += nwv) {
     int row, col;
@@ -793,25 +829,37 @@ k_bbox_records(DepthSrc src, FrameInfo* fi, float inv_xy, float inv_z, unsigned 
     const unsigned pix = (unsigned)row * (unsigned)src.w + (unsigned)col;
     float x = 0.f, y = 0.f, z = 0.f;
     const bool ok = row < src.h && col < src.w && depth_point_rc<FAST>(src, aff, frame, pix, row, col, x, y, z);
+    const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok);
     const float gx = floorf(x * inv_xy), gy = floorf(y * inv_xy), gz = floorf(z * inv_z);
+    const float dx = gx - rx, dy = gy - ry, dz = gz - rz;
+    const unsigned code = (unsigned)((int)dx + 1024) | ((unsigned)((int)dy + 1024) << 11) | ((unsigned)((int)dz + 512) << 22);
     if (ok) {
-      mn[0] = fminf(mn[0], x);
-      mn[1] = fminf(mn[1], y);
-      mn[2] = fminf(mn[2], z);
-      mx[0] = fmaxf(mx[0], x);
-      mx[1] = fmaxf(mx[1], y);
-      mx[2] = fmaxf(mx[2], z);
-      ++cnt;
+      mn[0] = min_nn(mn[0], x);
+      mn[1] = min_nn(mn[1], y);
+      mn[2] = min_nn(mn[2], z);
+      mx[0] = max_nn(mx[0], x);
+      mx[1] = max_nn(mx[1], y);
+      mx[2] = max_nn(mx[2], z);
     }
+    cnt += __popcll(okm);
+    // (every surviving pixel is tested, not the leaders only: the garbage code of a cell outside the range can equal
+    // the code of a cell inside it)
+    const bool out = ok && !(fabsf(dx) < 1024.f && fabsf(dy) < 1024.f && fabsf(dz) < 512.f);
     unsigned long long my_grp;
-    const unsigned ng = chunk_groups<true>(ok, gx, gy, gz, my_grp);
+    unsigned ng;
+    if (__builtin_amdgcn_ballot_w64(out)) {
+      // the call will be repeated in two passes, which keep these counts: count the groups the way k_group_records
+      // finds them (the records of this chunk are not used)
+      over = true;
+      ng = chunk_groups<false>(ok, gx, gy, gz, my_grp);
+      my_grp = 0ull;
+    } else {
+      ng = chunk_groups_code(okm, code, my_grp);
+    }
     const size_t cg = (size_t)frame * cpf + c;
     if (lane == 0) grp_cnt[cg] = ng;
-    const unsigned long long leaders = __ballot(my_grp != 0ull);
+    const unsigned long long leaders = __builtin_amdgcn_ballot_w64(my_grp != 0ull);
     if (my_grp) {
-      const float dx = gx - rx, dy = gy - ry, dz = gz - rz;
-      over |= !(fabsf(dx) < 1024.f && fabsf(dy) < 1024.f && fabsf(dz) < 512.f);
-      const unsigned code = (unsigned)((int)dx + 1024) | ((unsigned)((int)dy + 1024) << 11) | ((unsigned)((int)dz + 512) << 22);
       const unsigned rc0 = (((unsigned)row - (unsigned)(lane / kChunkCols)) << 16) | ((unsigned)col - (unsigned)(lane % kChunkCols));
       slots[cg * kChunk + (unsigned)__popcll(leaders & lt)] = make_uint4(code, (unsigned)my_grp, (unsigned)(my_grp >> 32), rc0);
     }
@@ -824,7 +872,6 @@ k_bbox_records(DepthSrc src, FrameInfo* fi, float inv_xy, float inv_z, unsigned 
       mn[d] = fminf(mn[d], __shfl_down(mn[d], off));
       mx[d] = fmaxf(mx[d], __shfl_down(mx[d], off));
     }
-    cnt += __shfl_down(cnt, off);
   }
   __shared__ float s_mn[kBlock / kWave][3], s_mx[kBlock / kWave][3];
   __shared__ int s_cnt[kBlock / kWave];

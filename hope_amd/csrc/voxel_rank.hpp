@@ -336,12 +336,47 @@ __device__ __forceinline__ void sort_small(ListPtr list, unsigned n)
   }
 }
 
+// the pixels of one image row of a record, or of two records side by side (m: bit b = column col0 + b), in ascending
+// column order, four depth
+// reads in flight per step.  All of it in 32-bit lane arithmetic: the kernel is bound by VALU issue, and the 64-bit
+// mask walk of centroid_add_bits costs twice the instructions per pixel.
+template <bool FAST>
+__device__ __forceinline__ void centroid_add_row(const DepthSrc& src, const float (&aff)[12], const uint16_t* dp,
+                                                 unsigned row, unsigned col0, unsigned m, float& sx, float& sy,
+                                                 float& sz)
+{
+  const uint16_t* rp = dp + (row * (unsigned)src.w + col0);  // (row, col0) is inside the image: the row has pixels
+  while (m) {
+    unsigned bb[4], dd[4];
+    bool on[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      on[i] = m != 0u;
+      bb[i] = on[i] ? (unsigned)__builtin_ctz(m) : 0u;
+      m &= m - 1u;  // (0 stays 0)
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dd[i] = rp[bb[i]];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (on[i]) {
+        float x, y, z;
+        depth_code_point<FAST>(src, aff, dd[i], row, col0 + bb[i], x, y, z);
+        sx += x;
+        sy += y;
+        sz += z;
+      }
+    }
+  }
+}
+
 template <bool FAST, class ListPtr>
 __device__ __forceinline__ void centroid_walk(const DepthSrc& src, const float (&aff)[12], int frame, ListPtr list,
                                               unsigned cnt, const uint4* rec, float& sx, float& sy, float& sz,
                                               unsigned& n)
 {
-  constexpr unsigned long long kRowMask = (kChunkCols == 64) ? ~0ull : ((1ull << (kChunkCols & 63)) - 1ull);
+  static_assert(kChunkCols == 16 && kChunkRows == 4, "row masks are taken as 16-bit quarters of the record's mask");
+  const uint16_t* dp = src.depth + (size_t)frame * src.ppf;
   unsigned r_lo, r_hi, r_rc;
   {
     const uint4 t = rec[list[0]];
@@ -371,13 +406,20 @@ __device__ __forceinline__ void centroid_walk(const DepthSrc& src, const float (
       }
       ++e1;
     }
-    const int n_rows = (e1 == e + 1u) ? 1 : kChunkRows;
-    for (int row = 0; row < n_rows; ++row) {
-      for (unsigned ee = e; ee < e1; ++ee) {
+    const unsigned row0 = r_rc >> 16, col0 = r_rc & 0xffffu;
+    // a voxel's second record of the band is nearly always the next chunk to the right: its row joins the first
+    // record's row as the upper half of one 32-bit mask, and the lanes of a wave stay in step (one walk per row)
+    const bool join = e1 >= e + 2u && (b_rc & 0xffffu) == col0 + (unsigned)kChunkCols;
+    const unsigned j_lo = join ? b_lo : 0u, j_hi = join ? b_hi : 0u;
+    const unsigned rest = e + (join ? 2u : 1u);
+    for (unsigned row = 0; row < (unsigned)kChunkRows; ++row) {
+      const unsigned sh = (row & 1u) * 16u;
+      const unsigned m = ((((row & 2u) ? r_hi : r_lo) >> sh) & 0xffffu) | ((((row & 2u) ? j_hi : j_lo) >> sh) << 16);
+      n += (unsigned)__popc(m);
+      centroid_add_row<FAST>(src, aff, dp, row0 + row, col0, m, sx, sy, sz);
+      for (unsigned ee = rest; ee < e1; ++ee) {
         unsigned m_lo, m_hi, m_rc;
-        if (ee == e) {
-          m_lo = r_lo; m_hi = r_hi; m_rc = r_rc;
-        } else if (ee == e + 1u) {
+        if (ee == e + 1u) {
           m_lo = b_lo; m_hi = b_hi; m_rc = b_rc;
         } else if (ee == e + 2u) {
           m_lo = c_lo; m_hi = c_hi; m_rc = c_rc;
@@ -385,10 +427,9 @@ __device__ __forceinline__ void centroid_walk(const DepthSrc& src, const float (
           const uint4 t = rec[list[ee]];
           m_lo = t.y; m_hi = t.z; m_rc = t.w;
         }
-        unsigned long long m = (unsigned long long)m_lo | ((unsigned long long)m_hi << 32);
-        if (n_rows > 1) m &= kRowMask << (row * kChunkCols);
-        n += (unsigned)__popcll(m);
-        centroid_add_bits<FAST>(src, aff, frame, m_rc, m, sx, sy, sz);
+        const unsigned mr = (((row & 2u) ? m_hi : m_lo) >> sh) & 0xffffu;
+        n += (unsigned)__popc(mr);
+        centroid_add_row<FAST>(src, aff, dp, row0 + row, m_rc & 0xffffu, mr, sx, sy, sz);
       }
     }
     e = e1;
