@@ -38,7 +38,7 @@ __device__ __forceinline__ unsigned grid_cell(const float4 p, const FrameInfo& F
 // tab[w] = (occupancy of cells 32 w .. 32 w + 31, occupied cells below 32 w); zeroed by the host.
 // The cells ascend along the array (that is what is being checked), so the lanes of a wave that share a word are
 // neighbours: their bits are OR-ed along the wave first and the last lane of each run issues the one atomic.
-__global__ void __launch_bounds__(kBlock)
+static __global__ void __launch_bounds__(kBlock)
 k_grid_mark(const float4* vox, unsigned n, const FrameInfo* fi, float inv_xy, float inv_z, uint2* tab, Globals* g)
 {
   const unsigned e = blockIdx.x * kBlock + threadIdx.x;
@@ -63,13 +63,13 @@ k_grid_mark(const float4* vox, unsigned n, const FrameInfo* fi, float inv_xy, fl
   if (ok && (lane == kWave - 1 || nw != w)) atomicOr(&tab[w].x, bits);
 }
 
-__global__ void __launch_bounds__(kBlock) k_grid_popc(const uint2* tab, unsigned n_words, uint32_t* cnt)
+static __global__ void __launch_bounds__(kBlock) k_grid_popc(const uint2* tab, unsigned n_words, uint32_t* cnt)
 {
   const unsigned w = blockIdx.x * kBlock + threadIdx.x;
   if (w < n_words) cnt[w] = (unsigned)__popc(tab[w].x);
 }
 
-__global__ void __launch_bounds__(kBlock) k_grid_pref(uint2* tab, unsigned n_words, const uint32_t* pref)
+static __global__ void __launch_bounds__(kBlock) k_grid_pref(uint2* tab, unsigned n_words, const uint32_t* pref)
 {
   const unsigned w = blockIdx.x * kBlock + threadIdx.x;
   if (w < n_words) tab[w].y = pref[w];

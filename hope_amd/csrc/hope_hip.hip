@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "depth_records.hpp"
 #include "neighbours.hpp"
 #include "prims.hpp"
 #include "upon_plane.hpp"
@@ -25,6 +26,13 @@
 #include "verify_big.hpp"
 #include "voxel_part.hpp"
 #include "grid_index.hpp"
+#include "neighbours_inst.hpp"
+
+#ifndef HOPE_ABLATE  // (the ablation build changes the kernels' bodies: it instantiates its own)
+namespace hope {
+HOPE_NEIGHBOUR_KERNELS(HOPE_KERNEL_ELSEWHERE)
+}  // namespace hope
+#endif
 
 using namespace hope;
 

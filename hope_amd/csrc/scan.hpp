@@ -44,7 +44,7 @@ __device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned* s_w, u
   return pre + inc - v;
 }
 
-__global__ void __launch_bounds__(kScanThreads) k_scan_reduce(const uint32_t* in, size_t n, uint32_t* sums)
+static __global__ void __launch_bounds__(kScanThreads) k_scan_reduce(const uint32_t* in, size_t n, uint32_t* sums)
 {
   __shared__ unsigned s_w[kScanThreads / 64 + 1];
   const size_t base = (size_t)blockIdx.x * kScanTile;
@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_reduce(const uint32_t* in
 }
 
 // one workgroup: exclusive scan of up to any number of sums, kScanTile at a time (in place)
-__global__ void __launch_bounds__(kScanThreads) k_scan_sums(uint32_t* sums, size_t n)
+static __global__ void __launch_bounds__(kScanThreads) k_scan_sums(uint32_t* sums, size_t n)
 {
   __shared__ unsigned s_w[kScanThreads / 64 + 1];
   unsigned carry = 0u;
@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_sums(uint32_t* sums, size
   }
 }
 
-__global__ void __launch_bounds__(kScanThreads)
+static __global__ void __launch_bounds__(kScanThreads)
 k_scan_apply(const uint32_t* in, size_t n, const uint32_t* sums, uint32_t* out)
 {
   __shared__ unsigned s_w[kScanThreads / 64 + 1];

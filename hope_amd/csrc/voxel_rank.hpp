@@ -14,7 +14,7 @@
 // by slot number (= chunk order: band of rows, then left to right) in LDS before it walks them, which is
 // the order the stable sort used to leave.
 #pragma once
-#include "kernels.hpp"
+#include "depth_records.hpp"
 
 namespace hope {
 
