@@ -917,7 +917,11 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
     hipLaunchKernelGGL(k_grid_pref, dim3(nblk(n_words)), dim3(kBlock), 0, s, grid_tab, n_words, (const uint32_t*)gcnt);
     prof_close(c, ST_COLTABLE, pm, 16.0 * n_vox + 8.0 * n_words);
   } else if (col_only && c->col_index_lds && c->h_glob->max_cols <= kCntCap && (size_t)n_vox <= (size_t)200000 * F) {
-    hipLaunchKernelGGL(k_column_index, dim3(F), dim3(kRankBlock), 0, s, d_vox, c->d_fi, F, c->inv_xy, n_vox, total_cols,
+    const size_t ci_lds = sizeof(unsigned) * (size_t)c->h_glob->max_cols;
+    if (ci_lds > ((size_t)48 << 10))
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_column_index), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)ci_lds));
+    hipLaunchKernelGGL(k_column_index, dim3(F), dim3(kRankBlock), ci_lds, s, d_vox, c->d_fi, F, c->inv_xy, n_vox, total_cols,
                        col_first, cv_in, spt);
     prof_close(c, ST_COLTABLE, pm, (16.0 + 16.0) * n_vox + 4.0 * total_cols);
   } else {
@@ -1200,12 +1204,17 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   ALLOC(edges, uint2, (size_t)n_fit * K);
   unsigned* d_n_edges = &c->d_glob->n_runs;  // free again after the voxel stage
   const dim3 uf_grid(std::max(1u, nblk(max_fit, kUfTile)), F);
+  const size_t uf_lds = sizeof(int) * std::min<size_t>(kUfTile, std::max<size_t>(max_fit, 1));  // the largest tile
   HIPCHK(hipMemsetAsync(d_n_edges, 0, sizeof(unsigned), s));
+  if (uf_lds > ((size_t)48 << 10))
+    HIPCHK(hipFuncSetAttribute(K == 8 ? reinterpret_cast<const void*>(&k_union_local<true>)
+                                      : reinterpret_cast<const void*>(&k_union_local<false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)uf_lds));
   if (K == 8)
-    hipLaunchKernelGGL(k_union_local<true>, uf_grid, dim3(kUfBlock), 0, s, knn, fit_pt, c->d_fi, K, c->cfg.th_z,
+    hipLaunchKernelGGL(k_union_local<true>, uf_grid, dim3(kUfBlock), uf_lds, s, knn, fit_pt, c->d_fi, K, c->cfg.th_z,
                        parent, cross, edges, d_n_edges);
   else
-    hipLaunchKernelGGL(k_union_local<false>, uf_grid, dim3(kUfBlock), 0, s, knn, fit_pt, c->d_fi, K, c->cfg.th_z,
+    hipLaunchKernelGGL(k_union_local<false>, uf_grid, dim3(kUfBlock), uf_lds, s, knn, fit_pt, c->d_fi, K, c->cfg.th_z,
                        parent, cross, edges, d_n_edges);
   hipLaunchKernelGGL(k_union_cross, dim3(gb), dim3(kBlock), 0, s, knn, cross, n_fit, K, parent, (c->ablate / 100) % 10);
   hipLaunchKernelGGL(k_flatten_roots, dim3(gb), dim3(kBlock), 0, s, parent, rank, n_fit, root, L);

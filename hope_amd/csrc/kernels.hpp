@@ -960,13 +960,14 @@ __global__ void __launch_bounds__(kUfBlock)
 k_union_local(const int* knn, const float4* fit_pt, const FrameInfo* fi, int K, float th_z, int* parent, uint32_t* cross,
               uint2* edges, unsigned* n_edges)
 {
-  __shared__ int s_par[kUfTile];
+  // (dynamic: as many entries as the batch's largest tile has points, so that frames of a few thousand fit points
+  // leave room for two workgroups per CU -- the kernel waits on gathers and LDS chases, not on issue)
+  extern __shared__ int s_par[];
   const FrameInfo& F = fi[blockIdx.y];
   if (blockIdx.x * (unsigned)kUfTile >= (unsigned)F.n_fit) return;
   const unsigned base = (unsigned)F.fit_start + blockIdx.x * (unsigned)kUfTile;
   const unsigned end = min(base + (unsigned)kUfTile, (unsigned)(F.fit_start + F.n_fit));
-#pragma unroll
-  for (int i = 0; i < kUfPer; ++i) s_par[threadIdx.x + i * kUfBlock] = threadIdx.x + i * kUfBlock;
+  for (unsigned i = threadIdx.x; i < end - base; i += kUfBlock) s_par[i] = (int)i;
   __syncthreads();
   for (int i = 0; i < kUfPer; ++i) {
     const int l = threadIdx.x + i * kUfBlock;

@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(kRankBlock)
 k_column_index(const float4* vox, const FrameInfo* fi, int n_frames, float inv_xy, unsigned n_vox_total,
                unsigned total_cols, uint32_t* col_first, uint32_t* idx_tmp, float4* spt)
 {
-  __shared__ unsigned s_cnt[kCntCap];
+  extern __shared__ unsigned s_cnt[];  // the batch's largest table (Globals::max_cols entries, at most kCntCap): two workgroups per CU when it is small
   __shared__ unsigned s_w[kRankBlock / kWave + 1];
   const FrameInfo& F = fi[blockIdx.x];
   const unsigned tid = threadIdx.x;
