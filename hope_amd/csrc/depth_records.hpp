@@ -332,7 +332,15 @@ __device__ __forceinline__ void frame_ref_cell(const float* aff, float inv_xy, f
   rz = floorf(aff[11] * inv_z);
 }
 
-template <bool FAST>
+__device__ __forceinline__ int floor_to_int(float v)  // (int)floorf(v) for |v| < 2^31
+{
+  int r;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+
+// FULL: the image is a whole number of chunks (no pixel of a chunk lies outside it)
+template <bool FAST, bool FULL>
 __global__ void __launch_bounds__(kBlock)
 k_bbox_records(DepthSrc src, FrameInfo* fi, float inv_xy, float inv_z, unsigned cpf, unsigned cpb, uint32_t* grp_cnt,
                uint4* slots, Globals* g)
@@ -347,6 +355,7 @@ k_bbox_records(DepthSrc src, FrameInfo* fi, float inv_xy, float inv_z, unsigned 
   for (int k = 0; k < 12; ++k) aff[k] = fi[frame].aff[k];
   float rx, ry, rz;
   frame_ref_cell(aff, inv_xy, inv_z, rx, ry, rz);
+  const unsigned bx = 1023u - (unsigned)(int)rx, by = 1023u - (unsigned)(int)ry, bz = 511u - (unsigned)(int)rz;
   const unsigned long long lt = (1ull << lane) - 1ull;
   float mn[3] = {INFINITY, INFINITY, INFINITY};
   float mx[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -357,11 +366,13 @@ k_bbox_records(DepthSrc src, FrameInfo* fi, float inv_xy, float inv_z, unsigned 
     chunk_rowcol(c, lane, cpb, row, col);
     const unsigned pix = (unsigned)row * (unsigned)src.w + (unsigned)col;
     float x = 0.f, y = 0.f, z = 0.f;
-    const bool ok = row < src.h && col < src.w && depth_point_rc<FAST>(src, aff, frame, pix, row, col, x, y, z);
+    const bool ok = (FULL || (row < src.h && col < src.w)) && depth_point_rc<FAST>(src, aff, frame, pix, row, col, x, y, z);
     const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok);
-    const float gx = floorf(x * inv_xy), gy = floorf(y * inv_xy), gz = floorf(z * inv_z);
-    const float dx = gx - rx, dy = gy - ry, dz = gz - rz;
-    const unsigned code = (unsigned)((int)dx + 1024) | ((unsigned)((int)dy + 1024) << 11) | ((unsigned)((int)dz + 512) << 22);
+    // cell relative to the camera's, + 1023: in range when it fits 0 .. 2046 (0 .. 1022 in z); the packed code holds
+    // the same offsets + 1, as before (floor and conversion in one instruction; integer from there on)
+    const unsigned ux = (unsigned)floor_to_int(x * inv_xy) + bx, uy = (unsigned)floor_to_int(y * inv_xy) + by,
+                   uz = (unsigned)floor_to_int(z * inv_z) + bz;
+    const unsigned code = (ux | (uy << 11) | (uz << 22)) + (1u | (1u << 11) | (1u << 22));
     if (ok) {
       mn[0] = min_nn(mn[0], x);
       mn[1] = min_nn(mn[1], y);
@@ -373,14 +384,14 @@ k_bbox_records(DepthSrc src, FrameInfo* fi, float inv_xy, float inv_z, unsigned 
     cnt += __popcll(okm);
     // (every surviving pixel is tested, not the leaders only: the garbage code of a cell outside the range can equal
     // the code of a cell inside it)
-    const bool out = ok && !(fabsf(dx) < 1024.f && fabsf(dy) < 1024.f && fabsf(dz) < 512.f);
+    const bool out = ok && !(ux <= 2046u && uy <= 2046u && uz <= 1022u);
     unsigned long long my_grp;
     unsigned ng;
     if (__builtin_amdgcn_ballot_w64(out)) {
       // the call will be repeated in two passes, which keep these counts: count the groups the way k_group_records
       // finds them (the records of this chunk are not used)
       over = true;
-      ng = chunk_groups<false>(ok, gx, gy, gz, my_grp);
+      ng = chunk_groups<false>(ok, floorf(x * inv_xy), floorf(y * inv_xy), floorf(z * inv_z), my_grp);
       my_grp = 0ull;
     } else {
       ng = chunk_groups_code(okm, code, my_grp);

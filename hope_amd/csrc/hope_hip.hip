@@ -297,6 +297,16 @@ namespace {
     }                                                               \
   } while (0)
 
+// exclusive scan of n words with the hand-written kernels of scan.hpp (scratch from the arena); in == out allowed
+inline hipError_t arena_scan_u32(hope_ctx* c, const uint32_t* in, uint32_t* out, size_t n, hipStream_t s)
+{
+  if (n == 0) return hipSuccess;
+  uint32_t* sums = static_cast<uint32_t*>(c->arena.alloc(sizeof(uint32_t) * scan_sums_words(n)));
+  if (!sums) return hipErrorOutOfMemory;
+  scan_exclusive_u32(in, out, n, sums, s);
+  return hipGetLastError();
+}
+
 // thresholds exactly as the reference derives them (plane_segment.cpp:46-50; host scalars)
 void derive_thresholds(hope_ctx* c)
 {
@@ -505,12 +515,16 @@ inline int launch_bbox(hope_ctx* c, const DepthSrc& src, size_t n_per_frame)
     c->one_pass = !c->two_pass && n_chunks * kChunk * sizeof(uint4) <= ((size_t)16 << 30);
     if (c->one_pass) {
       ALLOC(c->d_slots, uint4, n_chunks * kChunk);
-      if (c->fast_div)
-        hipLaunchKernelGGL(k_bbox_records<true>, dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi, c->inv_xy,
-                           c->inv_z, c->cpf, c->cpb, c->d_grp_cnt, c->d_slots, c->d_glob);
-      else
-        hipLaunchKernelGGL(k_bbox_records<false>, dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi, c->inv_xy,
-                           c->inv_z, c->cpf, c->cpb, c->d_grp_cnt, c->d_slots, c->d_glob);
+      const bool full = src.w % kChunkCols == 0 && src.h % kChunkRows == 0;
+#define HOPE_BBOX_RECORDS(FAST, FULL)                                                                                 \
+  hipLaunchKernelGGL((k_bbox_records<FAST, FULL>), dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi, c->inv_xy, \
+                     c->inv_z, c->cpf, c->cpb, c->d_grp_cnt, c->d_slots, c->d_glob)
+      if (c->fast_div) {
+        if (full) HOPE_BBOX_RECORDS(true, true); else HOPE_BBOX_RECORDS(true, false);
+      } else {
+        if (full) HOPE_BBOX_RECORDS(false, true); else HOPE_BBOX_RECORDS(false, false);
+      }
+#undef HOPE_BBOX_RECORDS
     } else if (c->fast_div)
       hipLaunchKernelGGL(k_bbox_groups<true>, dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi, c->inv_xy,
                          c->inv_z, c->cpf, c->cpb, c->d_grp_cnt);
@@ -531,9 +545,8 @@ inline int launch_bbox(hope_ctx* c, const DepthSrc& src, size_t n_per_frame)
 inline int scan_groups(hope_ctx* c, const DepthSrc& src, size_t n_per_frame)
 {
   if (!use_groups(c, src) || n_per_frame == 0) return HOPE_OK;
-  PrimAlloc pa{arena_alloc_cb, &c->arena};
   const size_t n_chunks = (size_t)c->cpf * c->n_frames;
-  HIPCHK(exclusive_scan_u32(pa, c->d_grp_cnt, c->d_grp_off, n_chunks + 1, c->stream));
+  HIPCHK(arena_scan_u32(c, c->d_grp_cnt, c->d_grp_off, n_chunks + 1, c->stream));
   HIPCHK(hipMemcpyAsync(&c->d_glob->n_groups, c->d_grp_off + n_chunks, sizeof(uint32_t), hipMemcpyDeviceToDevice,
                         c->stream));
   return HOPE_OK;
@@ -789,7 +802,7 @@ int stage_voxel(hope_ctx* c, const Src& src, size_t n_per_frame, int cell_bits, 
   c->n_vox_total = n_vox;
   if (n_vox == 0) return HOPE_OK;
   pm = prof_mark(c);
-  HIPCHK(exclusive_scan_u32(pa, run_cnt, run_start, n_vox, s));
+  HIPCHK(arena_scan_u32(c, run_cnt, run_start, n_vox, s));
   prof_close(c, ST_VRLE, pm, 8.0 * n_vox);
   ALLOC(d_vox, float4, n_vox);
   ALLOC(d_vox_frame, int, n_vox);
@@ -1028,7 +1041,7 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   if (!gate_fused)
     hipLaunchKernelGGL(k_fit_flags, dim3(nblk((size_t)n_vox + 1)), dim3(kBlock), 0, s, d_normals, n_vox, c->th_norm,
                        flags);
-  HIPCHK(exclusive_scan_u32(pa, flags, fscan, (size_t)n_vox + 1, s));
+  HIPCHK(arena_scan_u32(c, flags, fscan, (size_t)n_vox + 1, s));
   hipLaunchKernelGGL(k_frame_fit_ranges, dim3(nblk(F)), dim3(kBlock), 0, s, c->d_fi, F, fscan, c->d_glob);
   HIPCHK(hipMemcpyAsync(&c->d_glob->pad, fscan + n_vox, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
   prof_close(c, ST_FIT, pm, (16.0 + 4.0 + 4.0 + 4.0) * n_vox);
@@ -1092,7 +1105,7 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   if (!gate_fused)
     hipLaunchKernelGGL(k_fit_sorted_flags, dim3(nblk((size_t)n_vox + 1)), dim3(kBlock), 0, s, spt, fit_rank, n_vox,
                        sflags);
-  HIPCHK(exclusive_scan_u32(pa, sflags, fpos, (size_t)n_vox + 1, s));
+  HIPCHK(arena_scan_u32(c, sflags, fpos, (size_t)n_vox + 1, s));
   hipLaunchKernelGGL(k_fit_sorted_scatter, dim3(nblk(n_vox)), dim3(kBlock), 0, s, spt, fit_rank, sflags, fpos, n_vox,
                      spt_fit);
   hipLaunchKernelGGL(k_fit_col_table, dim3(nblk((size_t)total_cols + 1)), dim3(kBlock), 0, s, col_first, fpos,
@@ -2233,7 +2246,6 @@ HOPE_API int hope_get_transformed(hope_ctx* c, int frame, float* xyz, int32_t* s
   }
   const ArenaScope scope(c->arena);  // (scratch of this export only: given back on return)
   hipStream_t s = c->stream;
-  PrimAlloc pa{arena_alloc_cb, &c->arena};
   uint32_t *flags, *scan;
   float* d_xyz;
   int* d_src;
@@ -2244,13 +2256,13 @@ HOPE_API int hope_get_transformed(hope_ctx* c, int frame, float* xyz, int32_t* s
   if (c->src_kind == 1) {
     hipLaunchKernelGGL((k_valid_flags<DepthSrc>), dim3(nblk(n + 1)), dim3(kBlock), 0, s, c->dsrc, c->d_fi, frame,
                        flags);
-    HIPCHK(exclusive_scan_u32(pa, flags, scan, n + 1, s));
+    HIPCHK(arena_scan_u32(c, flags, scan, n + 1, s));
     hipLaunchKernelGGL((k_export_transformed<DepthSrc>), dim3(nblk(n)), dim3(kBlock), 0, s, c->dsrc, c->d_fi, frame,
                        scan, d_xyz, d_src);
   } else {
     hipLaunchKernelGGL((k_valid_flags<CloudSrc>), dim3(nblk(n + 1)), dim3(kBlock), 0, s, c->csrc, c->d_fi, frame,
                        flags);
-    HIPCHK(exclusive_scan_u32(pa, flags, scan, n + 1, s));
+    HIPCHK(arena_scan_u32(c, flags, scan, n + 1, s));
     hipLaunchKernelGGL((k_export_transformed<CloudSrc>), dim3(nblk(n)), dim3(kBlock), 0, s, c->csrc, c->d_fi, frame,
                        scan, d_xyz, d_src);
   }
@@ -2275,7 +2287,7 @@ int upon_plane(hope_ctx* c, const Src& src, size_t n, int frame, const float2* d
   ALLOC(flags, uint32_t, n + 1);
   ALLOC(scan, uint32_t, n + 1);
   hipLaunchKernelGGL((k_upon_flags<Src>), dim3(nblk(n + 1)), dim3(kBlock), 0, s, src, c->d_fi, frame, d_contour, flt, flags);
-  HIPCHK(exclusive_scan_u32(pa, flags, scan, n + 1, s));
+  HIPCHK(arena_scan_u32(c, flags, scan, n + 1, s));
   uint32_t n_keep = 0;
   HIPCHK(hipMemcpyAsync(&n_keep, scan + n, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));

@@ -4,7 +4,7 @@
 LIB=$(cd "$(dirname "$0")/.." && pwd)/hope_amd/csrc/libhope_hip_ablate.so
 [ -f "$LIB" ] || { echo "build it first: make -C hope_amd/csrc ablate"; exit 1; }
 for a in "$@"; do
-  HOPE_DEBUG=1 HOPE_DEBUG_ABLATE=$a timeout -k 10 100 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-cloud --no-stream --hip-lib "$LIB" > gpurun_out/abl_$a.log 2>&1 || exit 1
+  HOPE_DEBUG=1 HOPE_DEBUG_ABLATE=$a timeout -k 10 100 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-cloud --no-stream --no-two-ranges --hip-lib "$LIB" > gpurun_out/abl_$a.log 2>&1 || exit 1
   python3 - "$a" <<'PY'
 import json, sys
 a = sys.argv[1]

@@ -11,7 +11,7 @@ rc=$?
 tail -5 $O/pytest_$tag.log
 [ $rc -ne 0 ] && exit $rc
 for sb in ${SBS:-1}; do
-  timeout -k 10 200 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-cloud --no-stream --sub-batches $sb > $O/bench_${tag}_sb$sb.log 2>&1 || { tail -5 $O/bench_${tag}_sb$sb.log; exit 1; }
+  timeout -k 10 200 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-cloud --no-stream --no-two-ranges --sub-batches $sb > $O/bench_${tag}_sb$sb.log 2>&1 || { tail -5 $O/bench_${tag}_sb$sb.log; exit 1; }
   python - $O/bench_${tag}_sb$sb.log <<'PY'
 import json, sys
 d = json.loads([x for x in open(sys.argv[1]) if x.startswith('{')][-1])

@@ -12,7 +12,7 @@ for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
            "FETCH_SIZE TCC_EA_RDREQ_sum"; do
   i=$((i+1))
-  timeout -s KILL 150 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pmck_${tag}_$i -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-cloud --no-stream > $O/pmck_${tag}_$i.log 2>&1 || { tail -5 $O/pmck_${tag}_$i.log; exit 1; }
+  timeout -s KILL 150 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pmck_${tag}_$i -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-cloud --no-stream --no-two-ranges > $O/pmck_${tag}_$i.log 2>&1 || { tail -5 $O/pmck_${tag}_$i.log; exit 1; }
   echo "pass $i done"
 done
 python3 - $O $tag "$frag" <<'PY'

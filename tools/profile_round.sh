@@ -9,7 +9,7 @@ O=$R/gpurun_out
 timeout -k 10 400 python $R/bench.py > $O/bench_$tag.json 2> $O/bench_$tag.err || { tail -5 $O/bench_$tag.err; exit 1; }
 echo "bench done"
 cd /tmp && export TMPDIR=/tmp
-F="--no-cpu-baseline --no-cloud --no-stream"
+F="--no-cpu-baseline --no-cloud --no-stream --no-two-ranges"
 C="--workload cloud --no-cpu-baseline"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$tag -- python3 $R/bench.py --steps 3 --warmup 1 $F > $O/prof_$tag.log 2>&1 || { tail -5 $O/prof_$tag.log; exit 1; }
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cloud_$tag -- python3 $R/bench.py --steps 3 --warmup 1 $C > $O/prof_cloud_$tag.log 2>&1 || { tail -5 $O/prof_cloud_$tag.log; exit 1; }
