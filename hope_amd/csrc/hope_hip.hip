@@ -119,6 +119,31 @@ struct Arena {
   }
 };
 
+// Host vectors that HIP copies into and out of on every call live in pinned memory: a copy to or from pageable
+// memory goes through the driver's bounce buffer and holds the host (and, at the end of a call, the GPU) for tens of
+// microseconds per 100 KB.  Capacity is kept across calls, so the steady state allocates nothing.
+template <class T>
+struct PinnedAllocator {
+  typedef T value_type;
+  PinnedAllocator() = default;
+  template <class U>
+  PinnedAllocator(const PinnedAllocator<U>&) {}
+  T* allocate(size_t n)
+  {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, n * sizeof(T), hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      throw std::bad_alloc();
+    }
+    return static_cast<T*>(p);
+  }
+  void deallocate(T* p, size_t) { (void)hipHostFree(p); }
+  template <class U>
+  bool operator==(const PinnedAllocator<U>&) const { return true; }
+  template <class U>
+  bool operator!=(const PinnedAllocator<U>&) const { return false; }
+};
+
 struct ArenaScope {  // everything allocated while it lives is given back
   Arena& a;
   std::vector<size_t> m;
@@ -212,6 +237,9 @@ struct hope_ctx {
   int ablate = 0;             // timing experiments only (-DHOPE_ABLATE builds read HOPE_DEBUG_ABLATE): wrong results
   int pixel_sort = 0;         // test knob: depth frames through the per-pixel sort (the cloud path's voxel stage)
   int col_sort_z = 0;         // test knob HOPE_DEBUG_COLSORT_Z=1: z cell bits in the column sort key even for VoxelGrid output
+  int timeline = 0;           // HOPE_DEBUG_TIMELINE=1: host-side time marks of a call, printed to stderr when it returns
+  std::vector<std::pair<const char*, double>> marks;
+  std::chrono::steady_clock::time_point mark0;
   int seg_sort = 1;           // per-frame segmented sort of the group records (HOPE_DEBUG_SEGSORT=0: device-wide sort)
   int col_index_lds = 1;      // column index by a per-frame counting sort in LDS when the tables fit (HOPE_DEBUG_COL_INDEX=0: the radix sort)
   int todo_threads = 1;       // HOPE_DEBUG_TODO_THREADS=0: the k-NN leftovers over the coarse index by a wave each
@@ -238,8 +266,8 @@ struct hope_ctx {
   int src_kind = 0;  // 1 depth, 2 cloud
   DepthSrc dsrc{};
   CloudSrc csrc{};
-  std::vector<FrameInfo> h_fi;
-  std::vector<ClusterRec> h_rec;
+  std::vector<FrameInfo, PinnedAllocator<FrameInfo>> h_fi;
+  std::vector<ClusterRec, PinnedAllocator<ClusterRec>> h_rec;
   std::vector<hope_max_plane> h_max;
   std::vector<std::vector<int32_t>> h_max_members;  // RT winner: every member cluster, in max_plane_cloud_ order
   std::vector<int> h_nplanes;
@@ -361,8 +389,28 @@ __global__ void k_publish_globals(const Globals* d, Globals* h, unsigned* h_seq,
   }
 }
 
+inline void tl_mark(hope_ctx* c, const char* what)
+{
+  if (!c->timeline) return;
+  const auto now = std::chrono::steady_clock::now();
+  if (c->marks.empty()) c->mark0 = now;
+  c->marks.emplace_back(what, std::chrono::duration<double, std::micro>(now - c->mark0).count());
+}
+inline void tl_print(hope_ctx* c)
+{
+  if (!c->timeline) return;
+  double prev = 0.0;
+  for (const auto& m : c->marks) {
+    fprintf(stderr, "[timeline] %9.1f us (+%8.1f) %s\n", m.second, m.second - prev, m.first);
+    prev = m.second;
+  }
+  c->marks.clear();
+}
+
 int sync_globals(hope_ctx* c)
 {
+  tl_mark(c, "sync_globals: enter");
+  struct Leave { hope_ctx* c; ~Leave() { tl_mark(c, "sync_globals: leave"); } } leave{c};
   if (!c->mail_poll) {
     HIPCHK(hipMemcpyAsync(c->h_glob, c->d_glob, sizeof(Globals), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1379,6 +1427,7 @@ int run_pipeline(hope_ctx* c, const Src& src, size_t n_per_frame)
   const int F = c->n_frames;
   hipStream_t s = c->stream;
   const auto t0 = std::chrono::steady_clock::now();
+  tl_mark(c, "run_pipeline: enter");
   c->ref_ms = 0;
   c->prof.recs.clear();
   c->prof.used = 0;
@@ -1417,6 +1466,7 @@ int run_pipeline(hope_ctx* c, const Src& src, size_t n_per_frame)
   c->d_fi = d_fi;
   HIPCHK(hipMemcpyAsync(d_fi, c->h_fi.data(), sizeof(FrameInfo) * F, hipMemcpyHostToDevice, s));
   HIPCHK(hipMemsetAsync(c->d_glob, 0, sizeof(Globals), s));
+  tl_mark(c, "frame records uploaded");
 
   // ---- A1..A3 + bbox ------------------------------------------------------------------
   int st;
@@ -1489,9 +1539,12 @@ int run_pipeline(hope_ctx* c, const Src& src, size_t n_per_frame)
     if (st != HOPE_OK) return st;
     timed = c->n_fit_total > 0 && c->stop_stage == 0;  // (an early stop never records the closing event)
   }
+  tl_mark(c, "all launched");
   HIPCHK(hipMemcpyAsync(c->h_fi.data(), d_fi, sizeof(FrameInfo) * F, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
+  tl_mark(c, "final synchronise done");
   prof_collect(c);
+  tl_mark(c, "prof_collect done");
   if (timed) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, c->ev_a, c->ev_b) == hipSuccess) c->ref_ms = ms;
@@ -1503,6 +1556,7 @@ int run_pipeline(hope_ctx* c, const Src& src, size_t n_per_frame)
   else if (c->n_fit_total == 0)
     for (FrameInfo& fi : c->h_fi) fi.n_segments = fi.n_clusters = 0;
   rt_post(c);
+  tl_mark(c, "rt_post done");
   int worst = HOPE_OK;
   for (FrameInfo& fi : c->h_fi) {
     fi.status = fi.n_vox == 0 ? HOPE_EMPTY
@@ -1510,6 +1564,8 @@ int run_pipeline(hope_ctx* c, const Src& src, size_t n_per_frame)
     worst = std::max(worst, fi.status);
   }
   c->whole_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  tl_mark(c, "return");
+  tl_print(c);
   return worst;
 }
 
@@ -1619,6 +1675,8 @@ HOPE_API int hope_create(const hope_config* cfg, hope_ctx** out)
   c->col_sort_z = (knob && knob[0] == '1') ? 1 : 0;
   knob = debug_env("HOPE_DEBUG_SUB_MIN");
   if (knob && std::atoi(knob) >= 1) c->sub_min_frames = std::atoi(knob);
+  knob = debug_env("HOPE_DEBUG_TIMELINE");
+  c->timeline = (knob && knob[0] == '1') ? 1 : 0;
   knob = debug_env("HOPE_DEBUG_SEGSORT");
   c->seg_sort = (knob && knob[0] == '0') ? 0 : 1;
   knob = debug_env("HOPE_DEBUG_COL_INDEX");
