@@ -310,6 +310,8 @@ def run_frames(job):
 
     elapsed = job.timed(ctx, step)
     tot = job.totals(ctx, True)
+    prof = ctx.profile()
+    ctx.close()   # (its workspace goes back to the device before the second context below builds its own)
     el2 = None
     if not args.no_two_ranges and args.sub_batches <= 1 and F >= 128:
         # the same batch as two ranges of frames in flight (hope_config.sub_batches = 2): faster, but a kernel's
@@ -322,10 +324,10 @@ def run_frames(job):
             assert ctx2.segment_depth_device(ptr, W, H, F) >= 0
 
         el2 = job.timed(ctx2, step2)
-        del ctx2
+        ctx2.close()
     if job.rank != 0:
         return None
-    stages, roofline = stage_report(ctx.profile(), args.steps, "hbm_traffic.json")
+    stages, roofline = stage_report(prof, args.steps, "hbm_traffic.json")
     roofline["traffic_source"] = traffic_source("hbm_traffic.json")
     out = {
         "value": tot[0] * args.steps / elapsed, "unit": "points/s", "ms_per_step": 1e3 * elapsed / args.steps,
