@@ -200,7 +200,9 @@ __device__ __forceinline__ bool depth_point_rc(const DepthSrc& s, const float* a
 
 // Pass 1: bbox + survivor count per frame (getMinMax3D) and the number of groups per chunk.
 // Groups are found on the un-shifted cell triple floor(p * inv_leaf), which needs no bbox.
-template <bool FAST>
+// BOX false: the group counts only (the call fell back from k_bbox_records<.., DENSE>, which has already left the
+// bounding boxes and the survivor counts)
+template <bool FAST, bool BOX>
 __global__ void __launch_bounds__(kBlock)
 k_bbox_groups(DepthSrc src, FrameInfo* fi, float inv_xy, float inv_z, unsigned cpf, unsigned cpb, uint32_t* grp_cnt)
 {
@@ -234,6 +236,7 @@ k_bbox_groups(DepthSrc src, FrameInfo* fi, float inv_xy, float inv_z, unsigned c
     const unsigned ng = chunk_groups<false>(ok, gx, gy, gz, mg);
     if (lane == 0) grp_cnt[(size_t)frame * cpf + c] = ng;
   }
+  if (!BOX) return;
 #pragma unroll
   for (int off = kWave / 2; off > 0; off >>= 1) {
 #pragma unroll
@@ -332,6 +335,35 @@ __device__ __forceinline__ void frame_ref_cell(const float* aff, float inv_xy, f
   rz = floorf(aff[11] * inv_z);
 }
 
+constexpr unsigned kCountStride = 64u;  // words between the record counters of two frames: a cache line (an L2 channel) each
+// the n records a wave has staged in LDS go to the next free places of its frame's range; false: the range is full
+__device__ __forceinline__ bool dense_flush(const uint4* staged, unsigned n, int lane, int frame, unsigned cap_f,
+                                            uint32_t* rec_count, uint4* rec, uint32_t* codes, unsigned cpb)
+{
+  // (the records were written by other lanes of this wave: LDS runs a wave's instructions in order; the fences keep
+  // the compiler from moving the reads above the writes)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  unsigned base = 0u;
+  if (lane == 0) base = atomicAdd(&rec_count[(size_t)frame * kCountStride], n);
+  base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+  const bool fits = base + n <= cap_f;
+  if (fits) {
+    const size_t at = (size_t)frame * cap_f + base;
+    for (unsigned i = (unsigned)lane; i < n; i += (unsigned)kWave) {
+      const uint4 r = staged[i];
+      rec[at + i] = r;
+      codes[at + i] = r.x;
+      // the record's chunk number within the frame (its rank in pixel order), for k_voxel_rank's sort words
+      codes[(size_t)gridDim.y * cap_f + at + i] = (r.w >> 16) / (unsigned)kChunkRows * cpb + (r.w & 0xffffu) / (unsigned)kChunkCols;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();  // (the next chunk's records overwrite the staging area)
+  return fits;
+}
+
 __device__ __forceinline__ int floor_to_int(float v)  // (int)floorf(v) for |v| < 2^31
 {
   int r;
@@ -339,12 +371,22 @@ __device__ __forceinline__ int floor_to_int(float v)  // (int)floorf(v) for |v| 
   return r;
 }
 
-// FULL: the image is a whole number of chunks (no pixel of a chunk lies outside it)
-template <bool FAST, bool FULL>
+// FULL: the image is a whole number of chunks (no pixel of a chunk lies outside it).
+// DENSE: the records do not go to the sparse slots (and no group counts are written); a wave collects them in LDS
+// and claims room for kDenseCap of them at a time in its frame's range of `slots` (frame * cap_f onwards, cell codes
+// also on their own in `codes`) with one atomic on rec_count[frame].  The records of a frame then lie densely, in no
+// particular order -- which k_voxel_rank does not need, and k_centroids_lists restores per voxel from the records'
+// chunk positions -- and the scan of the counts and k_group_keys' pass over the sparse slots fall away.  A frame with
+// more than cap_f records, like a cell outside the code range, raises Globals::code_overflow (two passes then).
+constexpr int kDenseCap = 256;
+template <bool FAST, bool FULL, bool DENSE>
 __global__ void __launch_bounds__(kBlock)
 k_bbox_records(DepthSrc src, FrameInfo* fi, float inv_xy, float inv_z, unsigned cpf, unsigned cpb, uint32_t* grp_cnt,
-               uint4* slots, Globals* g)
+               uint4* slots, Globals* g, unsigned cap_f, uint32_t* rec_count, uint32_t* codes)
 {
+  __shared__ uint4 s_rec[DENSE ? kBlock / kWave : 1][DENSE ? kDenseCap : 1];
+  unsigned n_staged = 0u;  // (wave-uniform)
+  bool full_frame = false;
   const int frame = blockIdx.y;
   const int lane = threadIdx.x & (kWave - 1);
   // (the wave's number as a scalar: the chunk's row and column then come out of the scalar unit)
@@ -361,7 +403,10 @@ k_bbox_records(DepthSrc src, FrameInfo* fi, float inv_xy, float inv_z, unsigned 
   float mx[3] = {-INFINITY, -INFINITY, -INFINITY};
   int cnt = 0;  // (wave-uniform: survivors of the wave's chunks)
   bool over = false;
-  for (unsigned c = wv; c < cpf; c += nwv) {
+  // (a wave takes a run of consecutive chunks: its dense records then come from neighbouring voxels, which
+  // k_voxel_rank's LDS look-ups need: 0.57 -> 0.44 ms; a run per block with the waves taking turns: 0.49 ms)
+  const unsigned per_wave = (cpf + nwv - 1u) / nwv;
+  for (unsigned c = wv * per_wave, c_end = min(c + per_wave, cpf); c < c_end; ++c) {
     int row, col;
     chunk_rowcol(c, lane, cpb, row, col);
     const unsigned pix = (unsigned)row * (unsigned)src.w + (unsigned)col;
@@ -389,22 +434,33 @@ k_bbox_records(DepthSrc src, FrameInfo* fi, float inv_xy, float inv_z, unsigned 
     unsigned ng;
     if (__builtin_amdgcn_ballot_w64(out)) {
       // the call will be repeated in two passes, which keep these counts: count the groups the way k_group_records
-      // finds them (the records of this chunk are not used)
+      // finds them (the records of this chunk are not used; DENSE: the two passes count for themselves)
       over = true;
-      ng = chunk_groups<false>(ok, floorf(x * inv_xy), floorf(y * inv_xy), floorf(z * inv_z), my_grp);
+      ng = DENSE ? 0u : chunk_groups<false>(ok, floorf(x * inv_xy), floorf(y * inv_xy), floorf(z * inv_z), my_grp);
       my_grp = 0ull;
     } else {
       ng = chunk_groups_code(okm, code, my_grp);
     }
     const size_t cg = (size_t)frame * cpf + c;
-    if (lane == 0) grp_cnt[cg] = ng;
+    if (!DENSE && lane == 0) grp_cnt[cg] = ng;
     const unsigned long long leaders = __builtin_amdgcn_ballot_w64(my_grp != 0ull);
-    if (my_grp) {
-      const unsigned rc0 = (((unsigned)row - (unsigned)(lane / kChunkCols)) << 16) | ((unsigned)col - (unsigned)(lane % kChunkCols));
+    const unsigned rc0 = (((unsigned)row - (unsigned)(lane / kChunkCols)) << 16) | ((unsigned)col - (unsigned)(lane % kChunkCols));
+    if (DENSE) {
+      if (n_staged + ng > (unsigned)kDenseCap) {
+        full_frame |= !dense_flush(s_rec[threadIdx.x / kWave], n_staged, lane, frame, cap_f, rec_count, slots, codes, cpb);
+        n_staged = 0u;
+      }
+      if (my_grp)
+        s_rec[threadIdx.x / kWave][n_staged + (unsigned)__popcll(leaders & lt)] =
+            make_uint4(code, (unsigned)my_grp, (unsigned)(my_grp >> 32), rc0);
+      n_staged += ng;
+    } else if (my_grp) {
       slots[cg * kChunk + (unsigned)__popcll(leaders & lt)] = make_uint4(code, (unsigned)my_grp, (unsigned)(my_grp >> 32), rc0);
     }
   }
-  if (__any(over) && lane == 0) g->code_overflow = 1u;
+  if (DENSE && n_staged > 0u)
+    full_frame |= !dense_flush(s_rec[threadIdx.x / kWave], n_staged, lane, frame, cap_f, rec_count, slots, codes, cpb);
+  if ((__any(over) || full_frame) && lane == 0) g->code_overflow = 1u;
 #pragma unroll
   for (int off = kWave / 2; off > 0; off >>= 1) {
 #pragma unroll

@@ -259,6 +259,12 @@ struct hope_ctx {
   uint4* d_slots = nullptr;       // one-pass depth path: kChunk record slots per chunk (sparse)
   int two_pass = 0;               // test knob HOPE_DEBUG_TWO_PASS: k_bbox_groups + k_group_records
   bool one_pass = false;          // this call's records are in d_slots
+  bool dense = false;             // ... densely per frame (k_bbox_records<.., DENSE>), cap_f records at most; else kChunk slots per chunk
+  int dense_records = 1;          // HOPE_DEBUG_DENSE_RECORDS=0: the sparse slots + k_group_keys
+  int cap_mul = 16;               // HOPE_DEBUG_CAP_MUL: records per chunk that a frame's dense range has room for
+  unsigned cap_f = 0;
+  uint32_t* d_rec_count = nullptr;
+  uint32_t* d_codes = nullptr;
   Prof prof;
 
   // ---- state of the last call --------------------------------------------------------
@@ -561,23 +567,39 @@ inline int launch_bbox(hope_ctx* c, const DepthSrc& src, size_t n_per_frame)
     const unsigned bx = std::max(1u, std::min<unsigned>(nblk(c->cpf, (kBlock / kWave) * 16), 512u));
     // one pass (records into sparse slots) unless the knob or the size of the slot array says otherwise
     c->one_pass = !c->two_pass && n_chunks * kChunk * sizeof(uint4) <= ((size_t)16 << 30);
+    // dense records (no scan of group counts, no k_group_keys) feed k_voxel_rank only: the sort path needs the
+    // records in chunk order
+    c->cap_f = std::max(c->cpf * (unsigned)c->cap_mul, std::min(c->cpf * (unsigned)kChunk, 4096u));
+    c->dense = c->one_pass && c->voxel_rank && c->dense_records && (size_t)c->cap_f * F < ((size_t)1 << 31) &&
+               bits_for(c->cap_f) + bits_for(c->cpf) <= 32;  // (k_voxel_rank's sort words: chunk number | record index)
     if (c->one_pass) {
-      ALLOC(c->d_slots, uint4, n_chunks * kChunk);
       const bool full = src.w % kChunkCols == 0 && src.h % kChunkRows == 0;
-#define HOPE_BBOX_RECORDS(FAST, FULL)                                                                                 \
-  hipLaunchKernelGGL((k_bbox_records<FAST, FULL>), dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi, c->inv_xy, \
-                     c->inv_z, c->cpf, c->cpb, c->d_grp_cnt, c->d_slots, c->d_glob)
-      if (c->fast_div) {
-        if (full) HOPE_BBOX_RECORDS(true, true); else HOPE_BBOX_RECORDS(true, false);
+      if (c->dense) {
+        ALLOC(c->d_slots, uint4, (size_t)c->cap_f * F);
+        ALLOC(c->d_codes, uint32_t, (size_t)c->cap_f * F * 2);  // (cell codes, then chunk numbers)
+        ALLOC(c->d_rec_count, uint32_t, (size_t)F * kCountStride);
+        HIPCHK(hipMemsetAsync(c->d_rec_count, 0, sizeof(uint32_t) * (size_t)F * kCountStride, c->stream));
       } else {
-        if (full) HOPE_BBOX_RECORDS(false, true); else HOPE_BBOX_RECORDS(false, false);
+        ALLOC(c->d_slots, uint4, n_chunks * kChunk);
       }
+#define HOPE_BBOX_RECORDS(FAST, FULL, DENSE)                                                                          \
+  hipLaunchKernelGGL((k_bbox_records<FAST, FULL, DENSE>), dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi,     \
+                     c->inv_xy, c->inv_z, c->cpf, c->cpb, c->d_grp_cnt, c->d_slots, c->d_glob, c->cap_f,             \
+                     c->d_rec_count, c->d_codes)
+#define HOPE_BBOX_RECORDS2(FAST, FULL) \
+  if (c->dense) HOPE_BBOX_RECORDS(FAST, FULL, true); else HOPE_BBOX_RECORDS(FAST, FULL, false)
+      if (c->fast_div) {
+        if (full) { HOPE_BBOX_RECORDS2(true, true); } else { HOPE_BBOX_RECORDS2(true, false); }
+      } else {
+        if (full) { HOPE_BBOX_RECORDS2(false, true); } else { HOPE_BBOX_RECORDS2(false, false); }
+      }
+#undef HOPE_BBOX_RECORDS2
 #undef HOPE_BBOX_RECORDS
     } else if (c->fast_div)
-      hipLaunchKernelGGL(k_bbox_groups<true>, dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi, c->inv_xy,
+      hipLaunchKernelGGL((k_bbox_groups<true, true>), dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi, c->inv_xy,
                          c->inv_z, c->cpf, c->cpb, c->d_grp_cnt);
     else
-      hipLaunchKernelGGL(k_bbox_groups<false>, dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi, c->inv_xy,
+      hipLaunchKernelGGL((k_bbox_groups<false, true>), dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi, c->inv_xy,
                          c->inv_z, c->cpf, c->cpb, c->d_grp_cnt);
   } else if (depth8_ok(src)) {
     const unsigned bx = std::max(1u, std::min<unsigned>(nblk(n_per_frame / 8), 256u));
@@ -592,7 +614,7 @@ inline int launch_bbox(hope_ctx* c, const DepthSrc& src, size_t n_per_frame)
 // depth path: exclusive scan of the per-chunk group counts; the total lands in Globals
 inline int scan_groups(hope_ctx* c, const DepthSrc& src, size_t n_per_frame)
 {
-  if (!use_groups(c, src) || n_per_frame == 0) return HOPE_OK;
+  if (!use_groups(c, src) || n_per_frame == 0 || c->dense) return HOPE_OK;
   const size_t n_chunks = (size_t)c->cpf * c->n_frames;
   HIPCHK(arena_scan_u32(c, c->d_grp_cnt, c->d_grp_off, n_chunks + 1, c->stream));
   HIPCHK(hipMemcpyAsync(&c->d_glob->n_groups, c->d_grp_off + n_chunks, sizeof(uint32_t), hipMemcpyDeviceToDevice,
@@ -600,6 +622,27 @@ inline int scan_groups(hope_ctx* c, const DepthSrc& src, size_t n_per_frame)
   return HOPE_OK;
 }
 inline int scan_groups(hope_ctx*, const CloudSrc&, size_t) { return HOPE_OK; }
+
+// The dense records of this call cannot be used (a cell outside the code range, a frame with more records than its
+// range holds, a grid that k_voxel_rank does not take): count the groups for the two-pass path, whose records come
+// in chunk order.  The bounding boxes and survivor counts of k_bbox_records stay.
+inline int dense_fallback(hope_ctx* c, const DepthSrc& src, size_t n_per_frame)
+{
+  const int F = c->n_frames;
+  c->dense = false;
+  c->one_pass = false;
+  const unsigned bx = std::max(1u, std::min<unsigned>(nblk(c->cpf, (kBlock / kWave) * 16), 512u));
+  if (c->fast_div)
+    hipLaunchKernelGGL((k_bbox_groups<true, false>), dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi, c->inv_xy,
+                       c->inv_z, c->cpf, c->cpb, c->d_grp_cnt);
+  else
+    hipLaunchKernelGGL((k_bbox_groups<false, false>), dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi, c->inv_xy,
+                       c->inv_z, c->cpf, c->cpb, c->d_grp_cnt);
+  int st = scan_groups(c, src, n_per_frame);
+  if (st != HOPE_OK) return st;
+  return sync_globals(c);
+}
+inline int dense_fallback(hope_ctx*, const CloudSrc&, size_t) { return HOPE_OK; }
 
 inline int launch_bbox(hope_ctx* c, const CloudSrc& src, size_t n_per_frame)
 {
@@ -648,6 +691,8 @@ int stage_voxel_rank(hope_ctx* c, const DepthSrc& src, size_t n_per_frame, size_
 {
   const int F = c->n_frames;
   hipStream_t s = c->stream;
+  const bool dense = c->dense;  // (keys, vals unused: the records' codes and their own indices; M = the ranges' capacity)
+  if (dense) M = (size_t)c->cap_f * F;
   uint32_t *rec_vox, *rec_list, *vox_end, *vox_cnt, *block_first;
   ALLOC(block_first, uint32_t, (size_t)F + 1);
   ALLOC(rec_vox, uint32_t, M);
@@ -655,12 +700,21 @@ int stage_voxel_rank(hope_ctx* c, const DepthSrc& src, size_t n_per_frame, size_
   ALLOC(vox_end, uint32_t, M);
   ALLOC(vox_cnt, uint32_t, (size_t)F);
   size_t pm = prof_mark(c);
-  hipLaunchKernelGGL(k_voxel_rank, dim3(F), dim3(kRankBlock), 0, s, c->d_fi, c->cpf, c->d_grp_off, keys, vals,
-                     (cell_bits >= 32 ? 0xffffffffu : ((1u << cell_bits) - 1u)), rec_vox, rec_list, vox_end, vox_cnt);
-  hipLaunchKernelGGL(k_frame_vox_scan, dim3(1), dim3(kRankBlock), 0, s, c->d_fi, F, vox_cnt, block_first, c->d_glob);
-  prof_close(c, ST_VRANK, pm, (8.0 + 4.0 + 4.0) * M);
+  const unsigned cell_mask = cell_bits >= 32 ? 0xffffffffu : ((1u << cell_bits) - 1u);
+  if (dense)
+    hipLaunchKernelGGL(k_voxel_rank<true>, dim3(F), dim3(kRankBlock), 0, s, c->d_fi, c->cpf, c->d_grp_off,
+                       (const uint32_t*)c->d_codes, (const uint32_t*)nullptr, cell_mask, rec_vox, rec_list, vox_end,
+                       vox_cnt, c->cap_f, (const uint32_t*)c->d_rec_count, c->inv_xy, c->inv_z, bits_for(c->cap_f));
+  else
+    hipLaunchKernelGGL(k_voxel_rank<false>, dim3(F), dim3(kRankBlock), 0, s, c->d_fi, c->cpf, c->d_grp_off, keys, vals,
+                       cell_mask, rec_vox, rec_list, vox_end, vox_cnt, 0u, (const uint32_t*)nullptr, c->inv_xy, c->inv_z, 0);
+  hipLaunchKernelGGL(k_frame_vox_scan, dim3(1), dim3(kRankBlock), 0, s, c->d_fi, F, vox_cnt, block_first, c->d_glob,
+                     dense ? (const uint32_t*)c->d_rec_count : (const uint32_t*)nullptr);
+  prof_close(c, ST_VRANK, pm, (8.0 + 4.0 + 4.0) * (double)M);
   int st = sync_globals(c);
   if (st != HOPE_OK) return st;
+  const double n_rec = dense ? (double)c->h_glob->n_groups : (double)M;  // (dense: counted by k_frame_vox_scan)
+  if (dense && c->prof.on && !c->prof.recs.empty()) c->prof.recs.back().bytes = (8.0 + 4.0 + 4.0) * n_rec;
   const unsigned n_vox = c->h_glob->n_vox_total;
   c->n_vox_total = n_vox;
   if (n_vox == 0) return HOPE_OK;
@@ -668,13 +722,16 @@ int stage_voxel_rank(hope_ctx* c, const DepthSrc& src, size_t n_per_frame, size_
   ALLOC(d_vox_frame, int, n_vox);
   pm = prof_mark(c);
   const dim3 grid((c->h_glob->max_vox + kXcds - 1u) / kXcds * kXcds);  // (blocks of kBlock voxels, frame by frame; dealt to the XCDs by the kernel)
-  if (c->fast_div)
-    hipLaunchKernelGGL(k_centroids_lists<true>, grid, dim3(kBlock), 0, s, src, c->d_fi, F, block_first, c->cpf,
-                       c->d_grp_off, rec_list, vox_end, c->d_slots, d_vox, d_vox_frame);
-  else
-    hipLaunchKernelGGL(k_centroids_lists<false>, grid, dim3(kBlock), 0, s, src, c->d_fi, F, block_first, c->cpf,
-                       c->d_grp_off, rec_list, vox_end, c->d_slots, d_vox, d_vox_frame);
-  prof_close(c, ST_CENTROID, pm, (4.0 + 16.0) * M + 2.0 * (double)n_per_frame * F + (28.0 + 4.0) * n_vox);
+#define HOPE_CENTROIDS_LISTS(FAST, DENSE)                                                                              \
+  hipLaunchKernelGGL((k_centroids_lists<FAST, DENSE>), grid, dim3(kBlock), 0, s, src, c->d_fi, F, block_first, c->cpf, \
+                     c->d_grp_off, rec_list, vox_end, c->d_slots, d_vox, d_vox_frame, c->cap_f, bits_for(c->cap_f))
+  if (c->fast_div) {
+    if (dense) HOPE_CENTROIDS_LISTS(true, true); else HOPE_CENTROIDS_LISTS(true, false);
+  } else {
+    if (dense) HOPE_CENTROIDS_LISTS(false, true); else HOPE_CENTROIDS_LISTS(false, false);
+  }
+#undef HOPE_CENTROIDS_LISTS
+  prof_close(c, ST_CENTROID, pm, (4.0 + 16.0) * n_rec + 2.0 * (double)n_per_frame * F + (28.0 + 4.0) * n_vox);
   return HOPE_OK;
 }
 int stage_voxel_rank(hope_ctx*, const CloudSrc&, size_t, size_t, int, const uint32_t*, const uint32_t*, float4*&, int*&)
@@ -780,6 +837,8 @@ int stage_voxel(hope_ctx* c, const Src& src, size_t n_per_frame, int cell_bits, 
   if (!groups && F == 1 && sizeof(VK) == 4 && c->voxel_part && !(c->h_glob->any_overflow & 1u) &&
       cell_bits > kPartLow && N > 0)
     return stage_voxel_part(c, src, N, cell_bits, d_vox, d_vox_frame);
+  if (groups && c->dense)
+    return stage_voxel_rank(c, src, n_per_frame, 0, cell_bits, nullptr, nullptr, d_vox, d_vox_frame);
   const size_t M = groups ? (size_t)c->h_glob->n_groups : N;  // records to sort
   if (M == 0) {
     c->n_vox_total = 0;
@@ -1433,6 +1492,7 @@ int run_pipeline(hope_ctx* c, const Src& src, size_t n_per_frame)
   c->prof.used = 0;
   c->n_vox_total = c->n_fit_total = c->n_cl_total = 0;
   c->one_pass = false;
+  c->dense = false;
   c->d_slots = nullptr;
   c->h_rec.clear();
   c->h_nplanes.assign(F, 0);
@@ -1515,6 +1575,10 @@ int run_pipeline(hope_ctx* c, const Src& src, size_t n_per_frame)
   const int total_bits = cell_bits + bits_for((unsigned long long)F);
   float4* d_vox = nullptr;
   int* d_vox_frame = nullptr;
+  if (c->dense && (c->h_glob->code_overflow || c->h_glob->max_cells > (1ull << 24) || total_bits > 32)) {
+    st = dense_fallback(c, src, n_per_frame);
+    if (st != HOPE_OK) return st;
+  }
   if (n_per_frame > 0 && c->input_is_downsampled) {
     st = adopt_downsampled(c, src, n_per_frame, d_vox, d_vox_frame);
     if (st != HOPE_OK) return st;
@@ -1675,6 +1739,10 @@ HOPE_API int hope_create(const hope_config* cfg, hope_ctx** out)
   c->col_sort_z = (knob && knob[0] == '1') ? 1 : 0;
   knob = debug_env("HOPE_DEBUG_SUB_MIN");
   if (knob && std::atoi(knob) >= 1) c->sub_min_frames = std::atoi(knob);
+  knob = debug_env("HOPE_DEBUG_DENSE_RECORDS");
+  c->dense_records = (knob && knob[0] == '0') ? 0 : 1;
+  knob = debug_env("HOPE_DEBUG_CAP_MUL");
+  if (knob && std::atoi(knob) >= 1 && std::atoi(knob) <= kChunk) c->cap_mul = std::atoi(knob);
   knob = debug_env("HOPE_DEBUG_TIMELINE");
   c->timeline = (knob && knob[0] == '1') ? 1 : 0;
   knob = debug_env("HOPE_DEBUG_SEGSORT");

@@ -15,6 +15,7 @@
 // the order the stable sort used to leave.
 #pragma once
 #include "depth_records.hpp"
+#include "sortnet.hpp"
 
 namespace hope {
 
@@ -76,6 +77,26 @@ __device__ __forceinline__ void for_each_record(unsigned n, const uint32_t* a, B
   }
 }
 
+// the same over two arrays (b may be null: its values are then 0)
+template <class Body>
+__device__ __forceinline__ void for_each_record2(unsigned n, const uint32_t* a, const uint32_t* b, Body&& body)
+{
+  for (unsigned base = threadIdx.x; base < n; base += 4u * kRankBlock) {
+    unsigned x[4], y[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned o = base + (unsigned)u * kRankBlock;
+      x[u] = a[o < n ? o : n - 1u];
+      y[u] = b ? b[o < n ? o : n - 1u] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned o = base + (unsigned)u * kRankBlock;
+      if (o < n) body(o, x[u], y[u]);
+    }
+  }
+}
+
 __device__ __forceinline__ unsigned popc4(const uint4& q)
 {
   return (unsigned)(__popc(q.x) + __popc(q.y) + __popc(q.z) + __popc(q.w));
@@ -84,9 +105,14 @@ __device__ __forceinline__ unsigned popc4(const uint4& q)
 // grid = n_frames, block = kRankBlock.  keys: cell index of every record (low cell_bits bits of k_group_keys'
 // sort key), vals: its slot; both dense, in emission (chunk) order, the frame's records at
 // [grp_off[f * cpf], grp_off[(f + 1) * cpf]).
+// DENSE (k_bbox_records<.., true>): the frame's records at [f * cap_f, f * cap_f + rec_count[f]) in no particular
+// order, keys = their packed cell codes relative to the camera's cell (decoded here with the frame's grid), and a
+// record's value is its own index.
+template <bool DENSE>
 __global__ void __launch_bounds__(kRankBlock)
 k_voxel_rank(const FrameInfo* fi, unsigned cpf, const uint32_t* grp_off, const uint32_t* keys, const uint32_t* vals,
-             unsigned cell_mask, uint32_t* rec_vox, uint32_t* rec_list, uint32_t* vox_end, uint32_t* vox_cnt)
+             unsigned cell_mask, uint32_t* rec_vox, uint32_t* rec_list, uint32_t* vox_end, uint32_t* vox_cnt,
+             unsigned cap_f, const uint32_t* rec_count, float inv_xy, float inv_z, int id_bits)
 {
   __shared__ __attribute__((aligned(16))) unsigned s_mem[kRankLds];
   __shared__ unsigned s_w[kRankBlock / kWave + 1];
@@ -95,15 +121,32 @@ k_voxel_rank(const FrameInfo* fi, unsigned cpf, const uint32_t* grp_off, const u
   unsigned* counters = s_mem;           // kCntCap (after the ranks have been written)
   const int f = blockIdx.x;
   const unsigned tid = threadIdx.x;
-  const unsigned rec_base = grp_off[(size_t)f * cpf];
-  const unsigned n_rec = grp_off[(size_t)(f + 1) * cpf] - rec_base;
+  const unsigned rec_base = DENSE ? (unsigned)f * cap_f : grp_off[(size_t)f * cpf];
+  const unsigned n_rec = DENSE ? min(rec_count[(size_t)f * kCountStride], cap_f) : grp_off[(size_t)(f + 1) * cpf] - rec_base;
   if (n_rec == 0u) {
     if (tid == 0) vox_cnt[f] = 0u;
     return;
   }
+  // (DENSE) cell index of a packed code: the same arithmetic as k_group_keys
+  int b0 = 0, b1 = 0, b2 = 0, d0 = 0, d01 = 0;
+  if (DENSE) {
+    const FrameInfo& F = fi[f];
+    float rx, ry, rz;
+    frame_ref_cell(F.aff, inv_xy, inv_z, rx, ry, rz);
+    b0 = (int)rx - 1024 - F.min_b[0];
+    b1 = (int)ry - 1024 - F.min_b[1];
+    b2 = (int)rz - 512 - F.min_b[2];
+    d0 = F.div_b[0];
+    d01 = F.div_b[0] * F.div_b[1];
+  }
+  const auto cell_of = [&](unsigned k) -> unsigned {
+    if (!DENSE) return k & cell_mask;
+    const int i0 = (int)(k & 2047u) + b0, i1 = (int)((k >> 11) & 2047u) + b1, i2 = (int)(k >> 22) + b2;
+    return (unsigned)(i0 + i1 * d0 + i2 * d01);
+  };
   const unsigned cells = (unsigned)fi[f].cells;
   const uint32_t* key = keys + rec_base;
-  const uint32_t* val = vals + rec_base;
+  const uint32_t* val = DENSE ? nullptr : vals + rec_base;
   uint32_t* rvox = rec_vox + rec_base;
   const uint4* bm4 = reinterpret_cast<const uint4*>(bitmap);
   // ---- voxel of every record = rank of its cell among the occupied cells, one cell range at a time ----
@@ -114,7 +157,7 @@ k_voxel_rank(const FrameInfo* fi, unsigned cpf, const uint32_t* grp_off, const u
     for (unsigned i = tid; i < n_grp * kPfxEvery; i += kRankBlock) bitmap[i] = 0u;
     __syncthreads();
     for_each_record(n_rec, key, [&](unsigned, unsigned k) {
-      const unsigned idx = (k & cell_mask) - lo;
+      const unsigned idx = cell_of(k) - lo;
       if (idx < span) atomicOr(&bitmap[idx >> 5], 1u << (idx & 31u));
     });
     __syncthreads();
@@ -135,7 +178,7 @@ k_voxel_rank(const FrameInfo* fi, unsigned cpf, const uint32_t* grp_off, const u
     }
     __syncthreads();
     for_each_record(n_rec, key, [&](unsigned o, unsigned k) {
-      const unsigned idx = (k & cell_mask) - lo;
+      const unsigned idx = cell_of(k) - lo;
       if (idx < span) {
         const unsigned w = idx >> 5, sub = w & 7u;
         const uint4 qa = bm4[(w >> 3) * 2u], qb = bm4[(w >> 3) * 2u + 1u];
@@ -181,9 +224,12 @@ k_voxel_rank(const FrameInfo* fi, unsigned cpf, const uint32_t* grp_off, const u
       }
     }
     __syncthreads();
-    for_each_record(n_rec, rvox, [&](unsigned o, unsigned rv) {
+    // DENSE: a sort word, chunk number (the record's rank in pixel order) above the record's index in the frame's
+    // range (the second half of `keys` holds the chunk numbers): k_centroids_lists sorts a voxel's words
+    for_each_record2(n_rec, rvox, DENSE ? keys + (size_t)gridDim.x * cap_f + rec_base : nullptr,
+                     [&](unsigned o, unsigned rv, unsigned chunk) {
       const unsigned v = rv - vlo;
-      if (v < nv) rec_list[rec_base + atomicAdd(&counters[v], 1u)] = val[o];
+      if (v < nv) rec_list[rec_base + atomicAdd(&counters[v], 1u)] = DENSE ? ((chunk << id_bits) | o) : val[o];
     });
     __syncthreads();
     // counters[v] is now one past voxel v's last place
@@ -197,7 +243,8 @@ k_voxel_rank(const FrameInfo* fi, unsigned cpf, const uint32_t* grp_off, const u
 // range of every frame in the global down-sampled arrays (one workgroup)
 // also block_first[f] = first block of kBlock voxels of frame f in k_centroids_lists' grid (entry n_frames: all)
 __global__ void __launch_bounds__(kRankBlock)
-k_frame_vox_scan(FrameInfo* fi, int n_frames, const uint32_t* vox_cnt, uint32_t* block_first, Globals* g)
+k_frame_vox_scan(FrameInfo* fi, int n_frames, const uint32_t* vox_cnt, uint32_t* block_first, Globals* g,
+                 const uint32_t* rec_count = nullptr)  // (dense records: their total goes to Globals::n_groups)
 {
   __shared__ unsigned s_w[kRankBlock / kWave + 1];
   unsigned carry = 0u, bcarry = 0u;
@@ -219,6 +266,13 @@ k_frame_vox_scan(FrameInfo* fi, int n_frames, const uint32_t* vox_cnt, uint32_t*
     g->n_vox_total = carry;
     g->max_vox = bcarry;  // (blocks of the centroid kernel)
     block_first[n_frames] = bcarry;
+  }
+  if (rec_count) {
+    unsigned mine = 0u;
+    for (int f = (int)threadIdx.x; f < n_frames; f += kRankBlock) mine += rec_count[(size_t)f * kCountStride];
+    unsigned total;
+    block_scan_excl_1024(mine, s_w, total);
+    if (threadIdx.x == 0) g->n_groups = total;
   }
 }
 
@@ -439,11 +493,50 @@ __device__ __forceinline__ void centroid_walk(const DepthSrc& src, const float (
   }
 }
 
-template <bool FAST>
+// DENSE: the frame's records are those of k_bbox_records<.., true> (range f * cap_f of `rec`, any order)
+// a voxel's sort words (DENSE) into ascending order, then each replaced by the record index it carries.  Up to 16
+// words go through a sorting network in registers (the words arrive in no order: an insertion sort would move half
+// of them, lane by lane); all lanes of the wave call this.
+template <class ListPtr>
+__device__ __forceinline__ void sort_words(ListPtr list, unsigned n, unsigned id_mask, unsigned rec_base)
+{
+  const bool over8 = __any(n > 8u), over16 = __any(n > 16u);
+  if (n > 16u) {
+    sort_small(list, n);
+    for (unsigned i = 0; i < n; ++i) list[i] = rec_base + (list[i] & id_mask);
+    return;
+  }
+  (void)over16;
+  unsigned w[16];
+#define HOPE_CE(a, b)                         \
+  {                                           \
+    const unsigned lo_ = min(w[a], w[b]);     \
+    w[b] = max(w[a], w[b]);                   \
+    w[a] = lo_;                               \
+  }
+  if (!over8) {
+#pragma unroll
+    for (unsigned i = 0; i < 8u; ++i) w[i] = i < n ? list[i] : 0xffffffffu;
+    HOPE_SORT_NET8
+#pragma unroll
+    for (unsigned i = 0; i < 8u; ++i)
+      if (i < n) list[i] = rec_base + (w[i] & id_mask);
+  } else {
+#pragma unroll
+    for (unsigned i = 0; i < 16u; ++i) w[i] = i < n ? list[i] : 0xffffffffu;
+    HOPE_SORT_NET16
+#pragma unroll
+    for (unsigned i = 0; i < 16u; ++i)
+      if (i < n) list[i] = rec_base + (w[i] & id_mask);
+  }
+#undef HOPE_CE
+}
+
+template <bool FAST, bool DENSE>
 __global__ void __launch_bounds__(kBlock)
 k_centroids_lists(DepthSrc src, const FrameInfo* fi, int n_frames, const uint32_t* block_first, unsigned cpf,
                   const uint32_t* grp_off, uint32_t* rec_list, const uint32_t* vox_end, const uint4* rec, float4* vox,
-                  int* vox_frame)
+                  int* vox_frame, unsigned cap_f, int id_bits)
 {
   __shared__ unsigned s_list[kListCap];
   // Workgroups are dealt to the eight XCDs in turn, and each XCD has its own L2.  The voxels of a frame share
@@ -464,7 +557,7 @@ k_centroids_lists(DepthSrc src, const FrameInfo* fi, int n_frames, const uint32_
   const unsigned n_vox = (unsigned)F.n_vox;
   const unsigned v0 = (blk - block_first[frame]) * kBlock;
   if (v0 >= n_vox) return;
-  const unsigned rec_base = grp_off[(size_t)frame * cpf];
+  const unsigned rec_base = DENSE ? (unsigned)frame * cap_f : grp_off[(size_t)frame * cpf];
   const unsigned v = v0 + threadIdx.x;
   const bool live = v < n_vox;
   const unsigned v_last = min(v0 + (unsigned)kBlock, n_vox) - 1u;
@@ -480,14 +573,18 @@ k_centroids_lists(DepthSrc src, const FrameInfo* fi, int n_frames, const uint32_
   if (E - S <= (unsigned)kListCap) {  // (block-uniform)
     for (unsigned i = threadIdx.x; i < E - S; i += kBlock) s_list[i] = rec_list[rec_base + S + i];
     __syncthreads();
+    const unsigned id_mask = (1u << id_bits) - 1u;
+    if (DENSE) sort_words(s_list + (live ? start - S : 0u), cnt, id_mask, rec_base);  // (every lane: wave votes inside)
     if (live) {
       unsigned* list = s_list + (start - S);
-      sort_small(list, cnt);
+      if (!DENSE) sort_small(list, cnt);
       centroid_walk<FAST>(src, aff, frame, list, cnt, rec, sx, sy, sz, n);
     }
   } else if (live) {
     uint32_t* list = rec_list + rec_base + start;
     sort_small(list, cnt);
+    if (DENSE)
+      for (unsigned i = 0; i < cnt; ++i) list[i] = rec_base + (list[i] & ((1u << id_bits) - 1u));
     centroid_walk<FAST>(src, aff, frame, list, cnt, rec, sx, sy, sz, n);
   }
   if (live) {

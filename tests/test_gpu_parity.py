@@ -454,6 +454,30 @@ def test_depth_frames_through_two_passes(hip_lib, oracle_lib, monkeypatch):
         assert_frame_equal(o2, g2, f)
 
 
+def test_depth_group_records_dense_sparse_and_overflowing(hip_lib, oracle_lib, monkeypatch):
+    """The group records of a depth batch lie densely per frame by default (k_bbox_records<.., DENSE>: LDS staging,
+    one atomic per wave, sort words in k_voxel_rank).  HOPE_DEBUG_DENSE_RECORDS=0 keeps the sparse slots and
+    k_group_keys; HOPE_DEBUG_CAP_MUL=1 leaves a frame's range room for one record per chunk, so every frame overflows
+    it and the call falls back to the two passes with the bounding boxes it already has."""
+    depth, t, q = synth_frames(3, first=61)
+    o = HopeContext(oracle_lib)
+    o.set_frame_poses(t, q)
+    assert o.segment_depth(depth) == 0
+    for knob, val in (("HOPE_DEBUG_DENSE_RECORDS", "0"), ("HOPE_DEBUG_CAP_MUL", "1"), ("HOPE_DEBUG_CAP_MUL", "16")):
+        monkeypatch.setenv(knob, val)
+        g = HopeContext(hip_lib)
+        monkeypatch.delenv(knob)
+        g.set_frame_poses(t, q)
+        assert g.segment_depth(depth) == 0
+        for f in range(3):
+            assert_frame_equal(o, g, f)
+        o1 = HopeContext(oracle_lib)                 # (a second call on the same context, other batch size)
+        o1.set_frame_poses(t[:1], q[:1])
+        g.set_frame_poses(t[:1], q[:1])
+        assert o1.segment_depth(depth[:1]) == 0 and g.segment_depth(depth[:1]) == 0
+        assert_frame_equal(o1, g, 0)
+
+
 def test_voxelgrid_pass_through_of_a_wide_cloud(hip_lib, oracle_lib):
     """PCL's VoxelGrid refuses a grid of more than INT_MAX cells ("Leaf size is too small for the input
     dataset") and copies its input through (voxel_grid.hpp applyFilter); A6..A12 then run on the raw
