@@ -198,6 +198,19 @@ __device__ __forceinline__ bool depth_point_rc(const DepthSrc& s, const float* a
   return true;
 }
 
+// the same from a depth sample that has been fetched already (k_bbox_records reads one chunk ahead)
+template <bool FAST>
+__device__ __forceinline__ bool depth_point_d(const DepthSrc& s, const float* aff, unsigned d, int row, int col,
+                                              float& ox, float& oy, float& oz)
+{
+  const float z = div_const<FAST>((float)d, s.scale, s.rcp_scale);
+  if (!(z < s.max_d && z > s.min_d)) return false;
+  const float x = div_const<FAST>(((float)col - s.cx) * z, s.fx, s.rcp_fx);
+  const float y = div_const<FAST>(((float)row - s.cy) * z, s.fy, s.rcp_fy);
+  apply_affine(aff, x, y, z, ox, oy, oz);
+  return true;
+}
+
 // Pass 1: bbox + survivor count per frame (getMinMax3D) and the number of groups per chunk.
 // Groups are found on the un-shifted cell triple floor(p * inv_leaf), which needs no bbox.
 // BOX false: the group counts only (the call fell back from k_bbox_records<.., DENSE>, which has already left the
@@ -406,12 +419,25 @@ k_bbox_records(DepthSrc src, FrameInfo* fi, float inv_xy, float inv_z, unsigned 
   // (a wave takes a run of consecutive chunks: its dense records then come from neighbouring voxels, which
   // k_voxel_rank's LDS look-ups need: 0.57 -> 0.44 ms; a run per block with the waves taking turns: 0.49 ms)
   const unsigned per_wave = (cpf + nwv - 1u) / nwv;
-  for (unsigned c = wv * per_wave, c_end = min(c + per_wave, cpf); c < c_end; ++c) {
-    int row, col;
+  // the depth sample of the next chunk is fetched before this chunk's arithmetic (the kernel is bound by VALU issue:
+  // a wave that waits for its own load at the top of every chunk leaves issue slots empty)
+  const uint16_t* dp = src.depth + (size_t)frame * src.ppf;
+  const auto fetch = [&](unsigned c, int& row, int& col, bool& in) -> unsigned {
     chunk_rowcol(c, lane, cpb, row, col);
-    const unsigned pix = (unsigned)row * (unsigned)src.w + (unsigned)col;
+    in = FULL || (row < src.h && col < src.w);
+    return in ? (unsigned)dp[(unsigned)row * (unsigned)src.w + (unsigned)col] : 0u;
+  };
+  const unsigned c_begin = wv * per_wave, c_end = min(c_begin + per_wave, cpf);
+  int row_n = 0, col_n = 0;
+  bool in_n = false;
+  unsigned d_n = c_begin < c_end ? fetch(c_begin, row_n, col_n, in_n) : 0u;
+  for (unsigned c = c_begin; c < c_end; ++c) {
+    const int row = row_n, col = col_n;
+    const bool in = in_n;
+    const unsigned d = d_n;
+    if (c + 1u < c_end) d_n = fetch(c + 1u, row_n, col_n, in_n);
     float x = 0.f, y = 0.f, z = 0.f;
-    const bool ok = (FULL || (row < src.h && col < src.w)) && depth_point_rc<FAST>(src, aff, frame, pix, row, col, x, y, z);
+    const bool ok = in && depth_point_d<FAST>(src, aff, d, row, col, x, y, z);
     const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok);
     // cell relative to the camera's, + 1023: in range when it fits 0 .. 2046 (0 .. 1022 in z); the packed code holds
     // the same offsets + 1, as before (floor and conversion in one instruction; integer from there on)
