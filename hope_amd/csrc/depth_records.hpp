@@ -101,7 +101,7 @@ __device__ __forceinline__ bool depth_point(const DepthSrc& s, const float* aff,
 template <bool MASKS>
 __device__ __forceinline__ unsigned chunk_groups(bool ok, float gx, float gy, float gz, unsigned long long& my_grp)
 {
-  unsigned long long todo = __ballot(ok);
+  unsigned long long todo = __builtin_amdgcn_ballot_w64(ok);
   unsigned ng = 0;
   int g_lo = 0, g_hi = 0;  // this lane's group mask, written by v_writelane from the scalar ballot
   if (todo) {
@@ -115,7 +115,7 @@ __device__ __forceinline__ unsigned chunk_groups(bool ok, float gx, float gy, fl
       while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
         const unsigned k = (unsigned)__builtin_amdgcn_readlane((int)code, leader);
-        const unsigned long long grp = __ballot(code == k);
+        const unsigned long long grp = __builtin_amdgcn_ballot_w64(code == k);
         if (MASKS) {
           writelane_u64(grp, leader, g_lo, g_hi);
         }
@@ -126,7 +126,7 @@ __device__ __forceinline__ unsigned chunk_groups(bool ok, float gx, float gy, fl
       while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
         const float lx = readlane_f(gx, leader), ly = readlane_f(gy, leader), lz = readlane_f(gz, leader);
-        const unsigned long long grp = __ballot(ok && gx == lx && gy == ly && gz == lz) | (1ull << leader);
+        const unsigned long long grp = __builtin_amdgcn_ballot_w64(ok && gx == lx && gy == ly && gz == lz) | (1ull << leader);
         if (MASKS) {
           writelane_u64(grp, leader, g_lo, g_hi);
         }
@@ -317,7 +317,7 @@ k_group_records(DepthSrc src, const FrameInfo* fi, float inv_xy, float inv_z, in
     const float gx = floorf(x * inv_xy), gy = floorf(y * inv_xy), gz = floorf(z * inv_z);
     unsigned long long my_grp;
     chunk_groups<true>(ok, gx, gy, gz, my_grp);
-    const unsigned long long leaders = __ballot(my_grp != 0ull);
+    const unsigned long long leaders = __builtin_amdgcn_ballot_w64(my_grp != 0ull);
     if (my_grp) {
       const size_t cg = (size_t)frame * cpf + c;
       const unsigned o = grp_off[cg] + (unsigned)__popcll(leaders & lt);

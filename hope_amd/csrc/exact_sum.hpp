@@ -91,8 +91,8 @@ __device__ __forceinline__ void decompose(float a, int eu, bool& valid, int& I, 
 __device__ __forceinline__ int lane_q(bool use, int I, bool up, bool tie, int p_in, int* first_tie_delta)
 {
   const int base = I + (up ? 1 : 0);
-  const unsigned long long T = __ballot(use && tie);
-  const unsigned long long O = __ballot(use && !tie && (base & 1));
+  const unsigned long long T = __builtin_amdgcn_ballot_w64(use && tie);
+  const unsigned long long O = __builtin_amdgcn_ballot_w64(use && !tie && (base & 1));
   const unsigned long long lt = lanemask_lt();
   const unsigned long long Tl = T & lt;
   int par;
@@ -336,7 +336,7 @@ __device__ __forceinline__ void slow_block(State& st, float a, Stats* stats)
 {
   const int lane = threadIdx.x & 63;
   // a block of zeros leaves any sum as it is (s is never -0: it starts at +0 and x + (-x) = +0)
-  if (__ballot(a != 0.f) == 0ull) return;
+  if (__builtin_amdgcn_ballot_w64(a != 0.f) == 0ull) return;
   unsigned n_float = 0;
   int barren = 0;  // steps in a row in which no integer step was accepted
   int start = 0;
@@ -364,7 +364,7 @@ __device__ __forceinline__ void slow_block(State& st, float a, Stats* stats)
     const int q = lane_q(act && valid, I, up, tie, st.S & 1, nullptr);
     const int Sj = st.S + wave_incl_scan(q);
     const bool in = st.S > 0 ? (Sj >= kLoS && Sj <= kHiS) : (Sj <= -kLoS && Sj >= -kHiS);
-    const unsigned long long bad = __ballot(act && !(valid && in));
+    const unsigned long long bad = __builtin_amdgcn_ballot_w64(act && !(valid && in));
     const int first = bad ? __ffsll((long long)bad) - 1 : kBlk;
     if (first > start) {
       st.S = __builtin_amdgcn_readlane(Sj, first - 1);

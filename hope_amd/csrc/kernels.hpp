@@ -1026,7 +1026,7 @@ k_union_local(const int* knn, const float4* fit_pt, const FrameInfo* fi, int K, 
     const int l = threadIdx.x + i * kUfBlock;
     const unsigned g = base + l;
     const bool live = g < end;
-    if (__ballot(live) == 0ull) break;
+    if (__builtin_amdgcn_ballot_w64(live) == 0ull) break;
     const int r = live ? s_par[l] : 0;
     const float zg = live ? fit_pt[g].z : 0.f;
     int nb[8], rv[8];
@@ -1044,7 +1044,7 @@ k_union_local(const int* knn, const float4* fit_pt, const FrameInfo* fi, int K, 
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const bool emit = rv[j] != r && fabsf(zg - zv[j]) < th_z;
-      const unsigned long long em = __ballot(emit);
+      const unsigned long long em = __builtin_amdgcn_ballot_w64(emit);
       if (em) {
         unsigned o = 0;
         if (lane == __ffsll((long long)em) - 1) o = atomicAdd(n_edges, (unsigned)__popcll(em));
@@ -1065,18 +1065,18 @@ k_union_cross(const int* knn, const uint32_t* cross, unsigned n_fit, int K, int*
 {
   const unsigned g = blockIdx.x * kBlock + threadIdx.x;
   const uint32_t m = g < n_fit ? cross[g] : 0u;
-  if (__ballot(m != 0u) == 0ull || ablate == 2) return;
+  if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull || ablate == 2) return;
   const int lane = threadIdx.x & (kWave - 1);
   const int ra = m ? parent[g] : 0;
   for (int j = 0; j < K; ++j) {
     const bool on = (m >> j) & 1u;
-    unsigned long long todo = __ballot(on);
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(on);
     if (!todo) continue;
     const int rb = on ? parent[knn[(size_t)g * K + j]] : 0;
     while (todo) {
       const int leader = __ffsll((long long)todo) - 1;
       const int la = __shfl(ra, leader), lb = __shfl(rb, leader);
-      todo &= ~__ballot(on && ra == la && rb == lb);
+      todo &= ~__builtin_amdgcn_ballot_w64(on && ra == la && rb == lb);
       if (lane == leader && ablate != 1) {
         int a = la, b = lb;
         while (true) {
@@ -1099,12 +1099,12 @@ k_union_cross(const int* knn, const uint32_t* cross, unsigned n_fit, int K, int*
 // thousands of same-address atomics collapse to a handful.
 __device__ __forceinline__ void wave_atomic_min_by_key(int* table, int key, int val, bool active)
 {
-  unsigned long long todo = __ballot(active);
+  unsigned long long todo = __builtin_amdgcn_ballot_w64(active);
   while (todo) {
     const int leader = __ffsll((long long)todo) - 1;
     const int k = __shfl(key, leader);
     const bool mine = active && key == k;
-    const unsigned long long grp = __ballot(mine);
+    const unsigned long long grp = __builtin_amdgcn_ballot_w64(mine);
     int m = mine ? val : 0x7fffffff;
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) m = min(m, __shfl_xor(m, off));
@@ -1115,11 +1115,11 @@ __device__ __forceinline__ void wave_atomic_min_by_key(int* table, int key, int 
 
 __device__ __forceinline__ void wave_atomic_count_by_key(uint32_t* table, int key, bool active)
 {
-  unsigned long long todo = __ballot(active);
+  unsigned long long todo = __builtin_amdgcn_ballot_w64(active);
   while (todo) {
     const int leader = __ffsll((long long)todo) - 1;
     const int k = __shfl(key, leader);
-    const unsigned long long grp = __ballot(active && key == k);
+    const unsigned long long grp = __builtin_amdgcn_ballot_w64(active && key == k);
     if ((threadIdx.x & (kWave - 1)) == leader) atomicAdd(&table[k], (uint32_t)__popcll(grp));
     todo &= ~grp;
   }
@@ -1151,12 +1151,12 @@ k_cross_edges(const int* knn, const float4* fit_pt, const int* root, const int* 
   const unsigned g = blockIdx.x * kBlock + threadIdx.x;
   // (K8: the edges of a frame that fits one union tile were found by k_union_local)
   const bool live = g < n_fit && !(K8 && (unsigned)fi[fit_frame[g]].n_fit <= (unsigned)kUfTile);
-  if (__ballot(live) == 0ull) return;
+  if (__builtin_amdgcn_ballot_w64(live) == 0ull) return;
   const int r = live ? root[g] : 0;
   const float zg = live ? fit_pt[g].z : 0.f;
   const int lane = threadIdx.x & (kWave - 1);
   auto emit_edge = [&](bool emit, int rv) {
-    const unsigned long long em = __ballot(emit);
+    const unsigned long long em = __builtin_amdgcn_ballot_w64(emit);
     if (em) {
       unsigned o = 0;
       if (lane == __ffsll((long long)em) - 1) o = atomicAdd(n_edges, (unsigned)__popcll(em));
@@ -1184,7 +1184,7 @@ k_cross_edges(const int* knn, const float4* fit_pt, const int* root, const int* 
       em[j] = rv[j] != r && fabsf(zg - zv[j]) < th_z;
       any |= em[j];
     }
-    if (__ballot(any) == 0ull) return;
+    if (__builtin_amdgcn_ballot_w64(any) == 0ull) return;
 #pragma unroll
     for (int j = 0; j < 8; ++j) emit_edge(em[j], rv[j]);
   } else {

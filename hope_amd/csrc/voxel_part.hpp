@@ -63,10 +63,10 @@ __device__ __forceinline__ bool part_cell(const Src& src, const FrameInfo* fi, f
 // lanes of the wave whose `ok` is set and whose low `bits` bits of d equal this lane's
 __device__ __forceinline__ unsigned long long match_lanes(unsigned d, int bits, bool ok)
 {
-  unsigned long long same = __ballot(ok);
+  unsigned long long same = __builtin_amdgcn_ballot_w64(ok);
   for (int b = 0; b < bits; ++b) {
     const bool bit = (d >> b) & 1u;
-    const unsigned long long v = __ballot(bit);
+    const unsigned long long v = __builtin_amdgcn_ballot_w64(bit);
     same &= bit ? v : ~v;
   }
   return same;
@@ -286,7 +286,7 @@ k_part_finish_small(const float4* rec, const uint32_t* bstart, unsigned n_bucket
     const float fn = (float)cnt;
     out[lo + pos] = make_float4(ax / fn, ay / fn, az / fn, 0.f);
   }
-  const unsigned long long firsts = __ballot(first);
+  const unsigned long long firsts = __builtin_amdgcn_ballot_w64(first);
   if (lane == 0) vox_cnt[b] = (unsigned)__popcll(firsts);
 }
 
@@ -336,7 +336,7 @@ k_part_finish_big(const float4* rec, const uint32_t* bstart, unsigned n_buckets,
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         rank[k] = 0;
-        if (__ballot(ok[k]) == 0ull) continue;
+        if (__builtin_amdgcn_ballot_w64(ok[k]) == 0ull) continue;
         const unsigned d = __float_as_uint(r[k].w) & cmask;
         const unsigned long long same = match_lanes(d, kPartLow, ok[k]);
         const unsigned before = s_cnt[w][d];
@@ -425,7 +425,7 @@ k_part_finish_big(const float4* rec, const uint32_t* bstart, unsigned n_buckets,
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const bool occ = an[j] != 0u;
-      const unsigned long long m = __ballot(occ);
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(occ);
       __syncthreads();  // (s_scan: the readers of the previous use are done)
       if (lane == 0) s_scan[w] = (unsigned)__popcll(m);
       __syncthreads();
