@@ -260,6 +260,7 @@ struct hope_ctx {
   int two_pass = 0;               // test knob HOPE_DEBUG_TWO_PASS: k_bbox_groups + k_group_records
   bool one_pass = false;          // this call's records are in d_slots
   bool dense = false;             // ... densely per frame (k_bbox_records<.., DENSE>), cap_f records at most; else kChunk slots per chunk
+  int members_by_frame = 1;       // HOPE_DEBUG_MEMBERS_SORT=1: the member lists by radix sort always; 0: by frame always
   int dense_records = 1;          // HOPE_DEBUG_DENSE_RECORDS=0: the sparse slots + k_group_keys
   int cap_mul = 16;               // HOPE_DEBUG_CAP_MUL: records per chunk that a frame's dense range has room for
   unsigned cap_f = 0;
@@ -1384,7 +1385,7 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   hipLaunchKernelGGL(k_segment_flags, dim3(nblk((size_t)n_fit + 1)), dim3(kBlock), 0, s, cnt, n_fit,
                      c->cfg.min_cluster, seg_flags);
   HIPCHK(exclusive_scan_u32x3(pa, seg_flags, seg_scan, (size_t)n_fit + 1, s));
-  hipLaunchKernelGGL(k_frame_cluster_ranges, dim3(nblk(F)), dim3(kBlock), 0, s, c->d_fi, F, seg_scan);
+  hipLaunchKernelGGL(k_frame_cluster_ranges, dim3(nblk(F)), dim3(kBlock), 0, s, c->d_fi, F, seg_scan, c->d_glob);
   prof_close(c, ST_SEGMENTS, pm, (4.0 + 4.0 + 4.0 + 7 * 4.0) * n_fit);
   // the cluster count comes back together with the number of large clusters and their super blocks
   const int big_from = c->verify_big_from > 0 ? std::max(c->verify_big_from, 3) : INT_MAX;
@@ -1415,12 +1416,20 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   c->d_members = members;
   c->d_cl_first = cl_first;
   pm = prof_mark(c);
-  hipLaunchKernelGGL(k_point_clusters, dim3(gb), dim3(kBlock), 0, s, label, seg_flags, seg_scan, n_fit, n_cl, cid, mkey,
-                     mval);
+  // members by cluster, ascending index within each: a batch of frames walks its frames (one workgroup each: no
+  // sort); a single cloud sorts (cluster, index) pairs
+  const unsigned mfc = c->h_glob->max_frame_clusters;
+  const bool by_frame = c->members_by_frame && (F >= 64 || c->members_by_frame == 2) &&
+                        mfc <= (unsigned)kMemberClusters && (max_fit <= 65536u || c->members_by_frame == 2);
+  hipLaunchKernelGGL(k_point_clusters, dim3(gb), dim3(kBlock), 0, s, label, seg_flags, seg_scan, n_fit, n_cl, cid,
+                     by_frame ? (uint32_t*)nullptr : mkey, mval);
   if (n_cl > 0) {
-    HIPCHK(sort_pairs_u32(pa, mkey, mkey_s, mval, members, n_fit, bits_for(n_cl), s));
+    if (!by_frame) HIPCHK(sort_pairs_u32(pa, mkey, mkey_s, mval, members, n_fit, bits_for(n_cl), s));
     hipLaunchKernelGGL(k_cluster_heads, dim3(gb), dim3(kBlock), 0, s, cnt, seg_flags, seg_scan, seed_node,
                        fit_frame, c->d_fi, n_fit, cl_first, rec);
+    if (by_frame)
+      hipLaunchKernelGGL(k_members_by_frame, dim3(F), dim3(kBlock), 0, s, c->d_fi, (const int*)cid,
+                         (const uint32_t*)cl_first, bits_for(mfc > 0u ? mfc - 1u : 0u), members);
     prof_close(c, ST_SEGMENTS, pm, (4.0 + 4.0 + 2 * 8.0 + 2 * 8.0) * n_fit);
     pm = prof_mark(c);
     // ---- A10..A12 -------------------------------------------------------------------
@@ -1743,6 +1752,8 @@ HOPE_API int hope_create(const hope_config* cfg, hope_ctx** out)
   c->dense_records = (knob && knob[0] == '0') ? 0 : 1;
   knob = debug_env("HOPE_DEBUG_CAP_MUL");
   if (knob && std::atoi(knob) >= 1 && std::atoi(knob) <= kChunk) c->cap_mul = std::atoi(knob);
+  knob = debug_env("HOPE_DEBUG_MEMBERS_SORT");  // 1: always the sort; 0: never (when the clusters fit), however few frames
+  c->members_by_frame = knob ? (knob[0] == '1' ? 0 : 2) : 1;
   knob = debug_env("HOPE_DEBUG_TIMELINE");
   c->timeline = (knob && knob[0] == '1') ? 1 : 0;
   knob = debug_env("HOPE_DEBUG_SEGSORT");

@@ -51,6 +51,7 @@ struct Globals {  // scalars produced on device, read back at the sync points
   unsigned int n_vox_total;
   unsigned int pad;
   unsigned int n_groups;  // depth path: number of (chunk, voxel) group records
+  unsigned int max_frame_clusters;  // k_frame_cluster_ranges: most clusters in one frame
   unsigned int max_tiles; // largest per-frame count of 32x32-column super tiles (neighbours.hpp)
   unsigned int max_tiles16;  // ... of 16x16-column tiles
   unsigned int sum_tiles;    // super tiles of all frames (the host picks the tile side from the points per super tile)
@@ -142,6 +143,18 @@ __device__ __forceinline__ bool load_point(const CloudSrc& s, const FrameInfo* f
 
 __device__ __forceinline__ unsigned src_count(const DepthSrc& s) { return s.ppf; }
 __device__ __forceinline__ unsigned src_count(const CloudSrc& s) { return s.n; }
+
+// lanes of the wave whose `ok` is set and whose low `bits` bits of d equal this lane's
+__device__ __forceinline__ unsigned long long match_lanes(unsigned d, int bits, bool ok)
+{
+  unsigned long long same = __builtin_amdgcn_ballot_w64(ok);
+  for (int b = 0; b < bits; ++b) {
+    const bool bit = (d >> b) & 1u;
+    const unsigned long long v = __builtin_amdgcn_ballot_w64(bit);
+    same &= bit ? v : ~v;
+  }
+  return same;
+}
 
 // ---- K1: bbox + count per frame ------------------------------------------------------
 // pcl::getMinMax3D inside VoxelGrid::applyFilter.  grid = (blocks, n_frames).
@@ -1259,7 +1272,7 @@ k_segment_flags(const uint32_t* cnt, unsigned n_fit, int min_cluster, U3* flags)
   flags[r] = U3{c > 0u ? 1u : 0u, cl ? 1u : 0u, cl ? c : 0u};
 }
 
-static __global__ void k_frame_cluster_ranges(FrameInfo* fi, int n_frames, const U3* scan)
+static __global__ void k_frame_cluster_ranges(FrameInfo* fi, int n_frames, const U3* scan, Globals* g)
 {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= n_frames) return;
@@ -1268,6 +1281,7 @@ static __global__ void k_frame_cluster_ranges(FrameInfo* fi, int n_frames, const
   fi[f].n_segments = (int)(b.a - a.a);
   fi[f].cl_start = (int)a.b;
   fi[f].n_clusters = (int)(b.b - a.b);
+  atomicMax(&g->max_frame_clusters, b.b - a.b);
 }
 
 // cluster id of every fit point (-1: its segment was dropped by the size filter) and the
@@ -1281,8 +1295,88 @@ k_point_clusters(const int* label, const U3* flags, const U3* scan, unsigned n_f
   const int a = label[g];
   const int c = flags[a].b ? (int)scan[a].b : -1;
   cid[g] = c;
-  mkey[g] = c >= 0 ? (uint32_t)c : n_cl_total;
-  mval[g] = g;
+  if (mkey) {  // (null: the member lists are made frame by frame, no pairs to sort)
+    mkey[g] = c >= 0 ? (uint32_t)c : n_cl_total;
+    mval[g] = g;
+  }
+}
+
+// The member lists of a batch of frames without a sort: a cluster's members are the fit points of ONE frame in
+// ascending index, so one workgroup walks its frame's fit points, each of its four waves a quarter of them, 64 at a
+// time, and hands every point the next place of its cluster (the lanes of one step that share a cluster are ranked by
+// a vote; a first walk counts every cluster's members per quarter, which gives the quarters their first places).
+// Replaces the stable radix sort of (cluster, index) pairs when no frame has more than kMemberClusters clusters.
+// grid = n_frames, block = kBlock; bits: enough for the largest per-frame cluster count - 1.
+constexpr int kMemberClusters = 4096;
+template <bool PLACE>
+__device__ __forceinline__ void members_walk(const int* cid, unsigned first, unsigned end, int cl_start, int bits,
+                                             int lane, unsigned* next, uint32_t* members)
+{
+  // (four steps' cluster ids are fetched while the four before them are handled: a step is otherwise one round trip
+  // to memory)
+  constexpr int kU = 4;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  int c_next[kU];
+#pragma unroll
+  for (int u = 0; u < kU; ++u) {
+    const unsigned i = first + (unsigned)(u * kWave + lane);
+    c_next[u] = i < end ? cid[i] : -1;
+  }
+  for (unsigned i0 = first; i0 < end; i0 += kU * kWave) {
+    int cc[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      cc[u] = c_next[u];
+      const unsigned i = i0 + (unsigned)((kU + u) * kWave + lane);
+      c_next[u] = i < end ? cid[i] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const unsigned g = i0 + (unsigned)(u * kWave + lane);
+      const int c = cc[u];
+      const bool ok = c >= 0;
+      const unsigned local = ok ? (unsigned)(c - cl_start) : 0u;
+      const unsigned long long same = match_lanes(local, bits, ok);
+      const unsigned at = ok ? next[local] : 0u;
+      if (PLACE && ok) members[at + (unsigned)__popcll(same & lt)] = g;
+      // (LDS runs a wave's instructions in order, and only this wave touches its row of counters; the barriers keep
+      // the compiler from reordering the read and the write)
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      if (ok && (same & lt) == 0ull) next[local] = at + (unsigned)__popcll(same);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+static __global__ void __launch_bounds__(kBlock)
+k_members_by_frame(const FrameInfo* fi, const int* cid, const uint32_t* cl_first, int bits, uint32_t* members)
+{
+  constexpr int kW = kBlock / kWave;
+  __shared__ unsigned s_next[kW][kMemberClusters];
+  const FrameInfo& F = fi[blockIdx.x];
+  const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+  const unsigned ncl = (unsigned)F.n_clusters;
+  if (ncl == 0u) return;
+  for (unsigned c = threadIdx.x; c < ncl; c += kBlock)
+    for (int ww = 0; ww < kW; ++ww) s_next[ww][c] = 0u;
+  __syncthreads();
+  const unsigned base = (unsigned)F.fit_start, n = (unsigned)F.n_fit;
+  const unsigned per = ((n + kW - 1u) / kW + kWave - 1u) / kWave * kWave;  // a quarter, in whole steps
+  const unsigned first = min(base + (unsigned)w * per, base + n), end = min(first + per, base + n);
+  members_walk<false>(cid, first, end, F.cl_start, bits, lane, s_next[w], members);
+  __syncthreads();
+  for (unsigned c = threadIdx.x; c < ncl; c += kBlock) {
+    unsigned run = cl_first[(unsigned)F.cl_start + c];
+    for (int ww = 0; ww < kW; ++ww) {
+      const unsigned t = s_next[ww][c];
+      s_next[ww][c] = run;
+      run += t;
+    }
+  }
+  __syncthreads();
+  members_walk<true>(cid, first, end, F.cl_start, bits, lane, s_next[w], members);
 }
 
 struct ClusterRec {  // == hope_cluster

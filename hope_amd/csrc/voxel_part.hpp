@@ -60,18 +60,6 @@ __device__ __forceinline__ bool part_cell(const Src& src, const FrameInfo* fi, f
   return true;
 }
 
-// lanes of the wave whose `ok` is set and whose low `bits` bits of d equal this lane's
-__device__ __forceinline__ unsigned long long match_lanes(unsigned d, int bits, bool ok)
-{
-  unsigned long long same = __builtin_amdgcn_ballot_w64(ok);
-  for (int b = 0; b < bits; ++b) {
-    const bool bit = (d >> b) & 1u;
-    const unsigned long long v = __builtin_amdgcn_ballot_w64(bit);
-    same &= bit ? v : ~v;
-  }
-  return same;
-}
-
 // ---- counts[digit][chunk] of one pass ------------------------------------------------------------
 // FROM_SRC: the first pass reads the input; later passes read the records of the previous pass
 template <bool FROM_SRC, class Src>

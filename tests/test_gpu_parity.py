@@ -478,6 +478,28 @@ def test_depth_group_records_dense_sparse_and_overflowing(hip_lib, oracle_lib, m
         assert_frame_equal(o1, g, 0)
 
 
+def test_member_lists_by_frame_or_by_sort(hip_lib, oracle_lib, monkeypatch):
+    """The member lists of the clusters: batches of 64 frames and more hand every fit point its place frame by frame
+    (k_members_by_frame, one wave per frame), fewer frames and single clouds sort (cluster, index) pairs.
+    HOPE_DEBUG_MEMBERS_SORT forces either on frames and on a cloud."""
+    from hope_amd import synth
+    depth, t, q = synth_frames(5, first=23)
+    cloud = synth.make_multilevel_cloud(300000, first_index=5, device="cpu").numpy()
+    o = HopeContext(oracle_lib)
+    for knob in ("0", "1"):
+        monkeypatch.setenv("HOPE_DEBUG_MEMBERS_SORT", knob)
+        g = HopeContext(hip_lib)
+        monkeypatch.delenv("HOPE_DEBUG_MEMBERS_SORT")
+        for c in (g, o):
+            c.set_frame_poses(t, q)
+            assert c.segment_depth(depth) == 0
+        for f in range(5):
+            assert_frame_equal(o, g, f)
+        for c in (g, o):
+            assert c.segment_cloud(cloud) == 0
+        assert_frame_equal(o, g, 0)
+
+
 def test_voxelgrid_pass_through_of_a_wide_cloud(hip_lib, oracle_lib):
     """PCL's VoxelGrid refuses a grid of more than INT_MAX cells ("Leaf size is too small for the input
     dataset") and copies its input through (voxel_grid.hpp applyFilter); A6..A12 then run on the raw
