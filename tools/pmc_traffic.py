@@ -29,7 +29,8 @@ STAGE_OF = [  # kernel name fragment -> bench.py stage
     ("k_flatten_roots", "labels(union+sweeps)"), ("k_cross_edges", "labels(union+sweeps)"),
     ("k_label_", "labels(union+sweeps)"), ("k_segment_", "segments(scan+sort)"),
     ("k_frame_cluster", "segments(scan+sort)"), ("k_point_clusters", "segments(scan+sort)"),
-    ("k_cluster_heads", "segments(scan+sort)"), ("k_cluster_verify", "k_cluster_verify"),
+    ("k_cluster_heads", "segments(scan+sort)"), ("k_members_by_frame", "segments(scan+sort)"),
+    ("k_cluster_verify", "k_cluster_verify"),
 ]
 
 
