@@ -131,7 +131,7 @@ struct PinnedAllocator {
   T* allocate(size_t n)
   {
     void* p = nullptr;
-    if (hipHostMalloc(&p, n * sizeof(T), hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc(&p, n * sizeof(T), hipHostMallocPortable) != hipSuccess) {
       (void)hipGetLastError();
       throw std::bad_alloc();
     }

@@ -27,3 +27,8 @@ for i in range(4):
     t0 = time.perf_counter()
     ctx.segment_depth_device(depth.data_ptr(), W, H, F)
     print("call %d: %.3f ms" % (i, (time.perf_counter() - t0) * 1e3), file=sys.stderr)
+import numpy as np
+cells = np.array([np.prod(np.array(ctx.counts(f).grid, dtype=np.int64)) for f in range(F)])
+nv = np.array([ctx.counts(f).n_vox for f in range(F)])
+print("cells per frame: min %d median %d max %d; voxels per frame: median %d max %d" %
+      (cells.min(), np.median(cells), cells.max(), np.median(nv), nv.max()), file=sys.stderr)
