@@ -170,7 +170,7 @@ enum Stage {
 };
 const char* const kStageNames[ST_COUNT] = {
   "k_bbox", "k_frame_grid", "k_voxel_keys", "voxel_sort(rocprim)", "voxel_rle+scan(rocprim)", "k_voxel_rank", "k_part_count", "k_part_scatter", "k_part_finish", "k_centroids",
-  "k_column_keys", "column_sort(rocprim)", "k_column_table+gather", "k_normals", "fit_gate+compact", "fit_column_index", "k_knn",
+  "k_column_keys", "column_sort(rocprim)", "column_index", "k_normals", "fit_gate+compact", "fit_column_index", "k_knn",
   "k_knn_todo",
   "labels(union+sweeps)", "segments(scan+sort)", "k_cluster_verify"};
 static_assert(sizeof(kStageNames) / sizeof(kStageNames[0]) == ST_COUNT, "one name per stage");

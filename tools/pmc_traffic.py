@@ -18,11 +18,11 @@ from collections import defaultdict
 
 STAGE_OF = [  # kernel name fragment -> bench.py stage
     ("k_part_count", "k_part_count"), ("k_part_scatter", "k_part_scatter"), ("k_part_", "k_part_finish"),
-    ("k_grid_", "k_column_table+gather"), ("k_xs_", "k_cluster_verify"), ("k_big_", "k_cluster_verify"),
+    ("k_grid_", "column_index"), ("k_xs_", "k_cluster_verify"), ("k_big_", "k_cluster_verify"),
     ("k_bbox", "k_bbox"), ("k_frame_grid", "k_frame_grid"), ("k_group_records", "k_voxel_keys"),
     ("k_group_keys", "k_voxel_keys"), ("k_fit_sorted", "fit_column_index"), ("k_fit_col_table", "fit_column_index"),
-    ("k_voxel_rank", "k_voxel_rank"), ("k_frame_vox_scan", "k_voxel_rank"), ("k_voxel_keys", "k_voxel_keys"), ("k_centroids", "k_centroids"), ("k_column_keys", "k_column_keys"),
-    ("k_column_table", "k_column_table+gather"), ("k_gather_sorted", "k_column_table+gather"),
+    ("k_voxel_rank", "k_voxel_rank"), ("k_frame_vox_scan", "k_voxel_rank"), ("k_voxel_keys", "k_voxel_keys"), ("k_centroids", "k_centroids"), ("k_column_keys", "k_column_keys"), ("k_column_index", "column_index"),
+    ("k_column_table", "column_index"), ("k_gather_sorted", "column_index"),
     ("k_normals", "k_normals"), ("k_fit_", "fit_gate+compact"), ("k_frame_fit", "fit_gate+compact"),
     ("k_knn_todo", "k_knn_todo"), ("k_knn", "k_knn"), ("k_coarse", "k_knn_todo"), ("k_gather_coarse", "k_knn_todo"),
     ("k_seed_ranks", "labels(union+sweeps)"), ("k_union", "labels(union+sweeps)"),
