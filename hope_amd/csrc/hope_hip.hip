@@ -1436,8 +1436,15 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
     // a cluster holds points of one frame, so max_fit bounds its size: depth batches never take the second launch.
     // A floor or a wall gets longer tiles (more LDS per workgroup, so for these alone); running the two launches
     // side by side on two streams was measured and gains nothing over one after the other
+    uint32_t* v_order;
+    unsigned* v_ends;
+    ALLOC(v_order, uint32_t, n_cl);
+    ALLOC(v_ends, unsigned, 2);
+    HIPCHK(hipMemsetAsync(v_ends, 0, 2 * sizeof(unsigned), s));
+    hipLaunchKernelGGL(k_cluster_order, dim3(nblk(n_cl)), dim3(kBlock), 0, s, (const ClusterRec*)rec, n_cl, v_ends,
+                       v_order);
     hipLaunchKernelGGL(k_cluster_verify_b<kVTile>, dim3(n_cl), dim3(kBlock), 0, s, members, cl_first, fit_pt, fit_nrm,
-                       n_cl, c->th_angle, 0, big_from, rec);
+                       n_cl, c->th_angle, 0, big_from, rec, (const uint32_t*)v_order);
     if (n_big > 0) {
       int st = verify_big(c, n_cl, n_big, n_big_sb, big_from, members, cl_first, fit_pt, fit_nrm, rec);
       if (st != HOPE_OK) return st;

@@ -1616,18 +1616,33 @@ __device__ __forceinline__ unsigned block_sum_u32(unsigned v, unsigned* s_cnt)
   return r;
 }
 
+// The kernel below takes as long as its longest chain (a frame's floor: 10-20 000 members, three dependent passes of
+// 2.74 ns per member) -- when that chain starts at once.  In cluster order it starts whenever its frame comes up, so
+// the clusters are dealt to the workgroups long ones first: clusters of kVLong members and more from the front of
+// `order`, the others from the back (ends[0], ends[1]: zeroed by the host).
+constexpr int kVLong = 2048;
+static __global__ void __launch_bounds__(kBlock)
+k_cluster_order(const ClusterRec* rec, unsigned n_cl, unsigned* ends, uint32_t* order)
+{
+  const unsigned c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= n_cl) return;
+  const bool is_long = rec[c].size >= kVLong;
+  const unsigned pos = is_long ? atomicAdd(&ends[0], 1u) : n_cl - 1u - atomicAdd(&ends[1], 1u);
+  order[pos] = c;
+}
+
 template <int kVTile>
 __global__ void __launch_bounds__(kBlock)
 k_cluster_verify_b(const uint32_t* members, const uint32_t* cl_first, const float4* fit_pt, const float4* fit_nrm,
-                   unsigned n_cl, float th_angle, int size_from, int size_below, ClusterRec* rec)
+                   unsigned n_cl, float th_angle, int size_from, int size_below, ClusterRec* rec, const uint32_t* order)
 {
   constexpr int kVStride = kVTile + 4;  // LDS row stride: the 6 chain lanes hit different banks
   __shared__ __attribute__((aligned(16))) float s_v[2][6][kVStride];
   __shared__ float s_bc[8];
   __shared__ float s_red[kBlock / kWave];
   __shared__ unsigned s_cnt[kBlock / kWave];
-  const unsigned c = blockIdx.x;
-  if (c >= n_cl) return;
+  if (blockIdx.x >= n_cl) return;
+  const unsigned c = order[blockIdx.x];  // (k_cluster_order: the long chains start first)
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const bool chain_wave = tid < kWave;

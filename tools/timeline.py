@@ -32,3 +32,8 @@ cells = np.array([np.prod(np.array(ctx.counts(f).grid, dtype=np.int64)) for f in
 nv = np.array([ctx.counts(f).n_vox for f in range(F)])
 print("cells per frame: min %d median %d max %d; voxels per frame: median %d max %d" %
       (cells.min(), np.median(cells), cells.max(), np.median(nv), nv.max()), file=sys.stderr)
+ncl = np.array([ctx.counts(f).n_clusters for f in range(F)])
+nseg = np.array([ctx.counts(f).n_segments for f in range(F)])
+sizes = np.concatenate([ctx.clusters(f)['size'] for f in range(0, F, 16)])
+print("clusters per frame: median %d max %d total %d; segments total %d; cluster sizes (every 16th frame): n %d median %d p90 %d max %d, <=64: %d, <=384: %d" %
+      (np.median(ncl), ncl.max(), ncl.sum(), nseg.sum(), len(sizes), np.median(sizes), np.percentile(sizes, 90), sizes.max(), (sizes <= 64).sum(), (sizes <= 384).sum()), file=sys.stderr)
