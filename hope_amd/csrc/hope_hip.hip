@@ -261,11 +261,13 @@ struct hope_ctx {
   bool one_pass = false;          // this call's records are in d_slots
   bool dense = false;             // ... densely per frame (k_bbox_records<.., DENSE>), cap_f records at most; else kChunk slots per chunk
   int members_by_frame = 1;       // HOPE_DEBUG_MEMBERS_SORT=1: the member lists by radix sort always; 0: by frame always
+  int frame_order = 1;            // HOPE_DEBUG_FRAME_ORDER=0: the per-frame kernels take the frames in frame order
   int dense_records = 1;          // HOPE_DEBUG_DENSE_RECORDS=0: the sparse slots + k_group_keys
   int cap_mul = 16;               // HOPE_DEBUG_CAP_MUL: records per chunk that a frame's dense range has room for
   unsigned cap_f = 0;
   uint32_t* d_rec_count = nullptr;
   uint32_t* d_codes = nullptr;
+  uint32_t* d_frame_order = nullptr;  // frames by descending record count (dense records, 64..4096 frames), or null
   Prof prof;
 
   // ---- state of the last call --------------------------------------------------------
@@ -596,6 +598,11 @@ inline int launch_bbox(hope_ctx* c, const DepthSrc& src, size_t n_per_frame)
       }
 #undef HOPE_BBOX_RECORDS2
 #undef HOPE_BBOX_RECORDS
+      if (c->dense && c->frame_order && F >= 64 && F <= 4096) {
+        ALLOC(c->d_frame_order, uint32_t, (size_t)F);
+        hipLaunchKernelGGL(k_frame_order, dim3(nblk(F, kBlock / kWave)), dim3(kBlock), 0, c->stream, (const uint32_t*)c->d_rec_count,
+                           kCountStride, F, c->d_frame_order);
+      }
     } else if (c->fast_div)
       hipLaunchKernelGGL((k_bbox_groups<true, true>), dim3(bx, F), dim3(kBlock), 0, c->stream, src, c->d_fi, c->inv_xy,
                          c->inv_z, c->cpf, c->cpb, c->d_grp_cnt);
@@ -705,10 +712,12 @@ int stage_voxel_rank(hope_ctx* c, const DepthSrc& src, size_t n_per_frame, size_
   if (dense)
     hipLaunchKernelGGL(k_voxel_rank<true>, dim3(F), dim3(kRankBlock), 0, s, c->d_fi, c->cpf, c->d_grp_off,
                        (const uint32_t*)c->d_codes, (const uint32_t*)nullptr, cell_mask, rec_vox, rec_list, vox_end,
-                       vox_cnt, c->cap_f, (const uint32_t*)c->d_rec_count, c->inv_xy, c->inv_z, bits_for(c->cap_f));
+                       vox_cnt, c->cap_f, (const uint32_t*)c->d_rec_count, c->inv_xy, c->inv_z, bits_for(c->cap_f),
+                       (const uint32_t*)c->d_frame_order);
   else
     hipLaunchKernelGGL(k_voxel_rank<false>, dim3(F), dim3(kRankBlock), 0, s, c->d_fi, c->cpf, c->d_grp_off, keys, vals,
-                       cell_mask, rec_vox, rec_list, vox_end, vox_cnt, 0u, (const uint32_t*)nullptr, c->inv_xy, c->inv_z, 0);
+                       cell_mask, rec_vox, rec_list, vox_end, vox_cnt, 0u, (const uint32_t*)nullptr, c->inv_xy, c->inv_z, 0,
+                       (const uint32_t*)nullptr);
   hipLaunchKernelGGL(k_frame_vox_scan, dim3(1), dim3(kRankBlock), 0, s, c->d_fi, F, vox_cnt, block_first, c->d_glob,
                      dense ? (const uint32_t*)c->d_rec_count : (const uint32_t*)nullptr);
   prof_close(c, ST_VRANK, pm, (8.0 + 4.0 + 4.0) * (double)M);
@@ -1043,7 +1052,7 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_column_index), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)ci_lds));
     hipLaunchKernelGGL(k_column_index, dim3(F), dim3(kRankBlock), ci_lds, s, d_vox, c->d_fi, F, c->inv_xy, n_vox, total_cols,
-                       col_first, cv_in, spt);
+                       col_first, cv_in, spt, (const uint32_t*)c->d_frame_order);
     prof_close(c, ST_COLTABLE, pm, (16.0 + 16.0) * n_vox + 4.0 * total_cols);
   } else {
   hipLaunchKernelGGL((k_column_keys<CK>), dim3(nblk(n_vox)), dim3(kBlock), 0, s, d_vox, d_vox_frame, c->d_fi,
@@ -1333,10 +1342,10 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)uf_lds));
   if (K == 8)
     hipLaunchKernelGGL(k_union_local<true>, uf_grid, dim3(kUfBlock), uf_lds, s, knn, fit_pt, c->d_fi, K, c->cfg.th_z,
-                       parent, cross, edges, d_n_edges);
+                       parent, cross, edges, d_n_edges, (const uint32_t*)nullptr);  // (frame order: 0.76 -> 0.83 ms here)
   else
     hipLaunchKernelGGL(k_union_local<false>, uf_grid, dim3(kUfBlock), uf_lds, s, knn, fit_pt, c->d_fi, K, c->cfg.th_z,
-                       parent, cross, edges, d_n_edges);
+                       parent, cross, edges, d_n_edges, (const uint32_t*)nullptr);  // (frame order: 0.76 -> 0.83 ms here)
   hipLaunchKernelGGL(k_union_cross, dim3(gb), dim3(kBlock), 0, s, knn, cross, n_fit, K, parent, (c->ablate / 100) % 10);
   hipLaunchKernelGGL(k_flatten_roots, dim3(gb), dim3(kBlock), 0, s, parent, rank, n_fit, root, L);
   if (K == 8)
@@ -1429,7 +1438,8 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
                        fit_frame, c->d_fi, n_fit, cl_first, rec);
     if (by_frame)
       hipLaunchKernelGGL(k_members_by_frame, dim3(F), dim3(kBlock), 0, s, c->d_fi, (const int*)cid,
-                         (const uint32_t*)cl_first, bits_for(mfc > 0u ? mfc - 1u : 0u), members);
+                         (const uint32_t*)cl_first, bits_for(mfc > 0u ? mfc - 1u : 0u), members,
+                         (const uint32_t*)c->d_frame_order);
     prof_close(c, ST_SEGMENTS, pm, (4.0 + 4.0 + 2 * 8.0 + 2 * 8.0) * n_fit);
     pm = prof_mark(c);
     // ---- A10..A12 -------------------------------------------------------------------
@@ -1509,6 +1519,7 @@ int run_pipeline(hope_ctx* c, const Src& src, size_t n_per_frame)
   c->n_vox_total = c->n_fit_total = c->n_cl_total = 0;
   c->one_pass = false;
   c->dense = false;
+  c->d_frame_order = nullptr;
   c->d_slots = nullptr;
   c->h_rec.clear();
   c->h_nplanes.assign(F, 0);
@@ -1761,6 +1772,8 @@ HOPE_API int hope_create(const hope_config* cfg, hope_ctx** out)
   if (knob && std::atoi(knob) >= 1 && std::atoi(knob) <= kChunk) c->cap_mul = std::atoi(knob);
   knob = debug_env("HOPE_DEBUG_MEMBERS_SORT");  // 1: always the sort; 0: never (when the clusters fit), however few frames
   c->members_by_frame = knob ? (knob[0] == '1' ? 0 : 2) : 1;
+  knob = debug_env("HOPE_DEBUG_FRAME_ORDER");
+  c->frame_order = (knob && knob[0] == '0') ? 0 : 1;
   knob = debug_env("HOPE_DEBUG_TIMELINE");
   c->timeline = (knob && knob[0] == '1') ? 1 : 0;
   knob = debug_env("HOPE_DEBUG_SEGSORT");

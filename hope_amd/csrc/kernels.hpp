@@ -971,12 +971,12 @@ __device__ __forceinline__ uint32_t mutual_edges_up(const int* knn, const float4
 template <bool K8>
 __global__ void __launch_bounds__(kUfBlock)
 k_union_local(const int* knn, const float4* fit_pt, const FrameInfo* fi, int K, float th_z, int* parent, uint32_t* cross,
-              uint2* edges, unsigned* n_edges)
+              uint2* edges, unsigned* n_edges, const uint32_t* order)
 {
   // (dynamic: as many entries as the batch's largest tile has points, so that frames of a few thousand fit points
   // leave room for two workgroups per CU -- the kernel waits on gathers and LDS chases, not on issue)
   extern __shared__ int s_par[];
-  const FrameInfo& F = fi[blockIdx.y];
+  const FrameInfo& F = fi[order ? order[blockIdx.y] : blockIdx.y];
   if (blockIdx.x * (unsigned)kUfTile >= (unsigned)F.n_fit) return;
   const unsigned base = (unsigned)F.fit_start + blockIdx.x * (unsigned)kUfTile;
   const unsigned end = min(base + (unsigned)kUfTile, (unsigned)(F.fit_start + F.n_fit));
@@ -1272,6 +1272,28 @@ k_segment_flags(const uint32_t* cnt, unsigned n_fit, int min_cluster, U3* flags)
   flags[r] = U3{c > 0u ? 1u : 0u, cl ? 1u : 0u, cl ? c : 0u};
 }
 
+// The kernels that run one workgroup per frame (k_voxel_rank, k_column_index, k_union_local, k_members_by_frame) take
+// 4 frames per CU on a 1024-frame batch whose frames differ 5x in size: dealt in frame order, a large frame that comes
+// up last is a tail as long as itself.  order[] = the frames by descending key (key: a count per frame at a stride,
+// e.g. its group records), ties by frame number; n^2 compares, a wave per frame (n_frames <= 4096).
+static __global__ void __launch_bounds__(kBlock)
+k_frame_order(const uint32_t* key, unsigned stride, int n_frames, uint32_t* order)
+{
+  // one wave per frame: its place = the frames with a larger key, or the same key and a smaller number
+  const int f = (int)(blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave);
+  const int lane = threadIdx.x & (kWave - 1);
+  if (f >= n_frames) return;
+  const unsigned k = key[(size_t)f * stride];
+  unsigned before = 0u;
+  for (int o = lane; o < n_frames; o += kWave) {
+    const unsigned ko = key[(size_t)o * stride];
+    before += (ko > k || (ko == k && o < f)) ? 1u : 0u;
+  }
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) before += (unsigned)__shfl_down((int)before, off);
+  if (lane == 0) order[before] = (uint32_t)f;
+}
+
 static __global__ void k_frame_cluster_ranges(FrameInfo* fi, int n_frames, const U3* scan, Globals* g)
 {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1351,11 +1373,12 @@ __device__ __forceinline__ void members_walk(const int* cid, unsigned first, uns
 }
 
 static __global__ void __launch_bounds__(kBlock)
-k_members_by_frame(const FrameInfo* fi, const int* cid, const uint32_t* cl_first, int bits, uint32_t* members)
+k_members_by_frame(const FrameInfo* fi, const int* cid, const uint32_t* cl_first, int bits, uint32_t* members,
+                   const uint32_t* order)
 {
   constexpr int kW = kBlock / kWave;
   __shared__ unsigned s_next[kW][kMemberClusters];
-  const FrameInfo& F = fi[blockIdx.x];
+  const FrameInfo& F = fi[order ? order[blockIdx.x] : blockIdx.x];
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
   const unsigned ncl = (unsigned)F.n_clusters;
   if (ncl == 0u) return;

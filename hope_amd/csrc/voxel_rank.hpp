@@ -112,14 +112,15 @@ template <bool DENSE>
 __global__ void __launch_bounds__(kRankBlock)
 k_voxel_rank(const FrameInfo* fi, unsigned cpf, const uint32_t* grp_off, const uint32_t* keys, const uint32_t* vals,
              unsigned cell_mask, uint32_t* rec_vox, uint32_t* rec_list, uint32_t* vox_end, uint32_t* vox_cnt,
-             unsigned cap_f, const uint32_t* rec_count, float inv_xy, float inv_z, int id_bits)
+             unsigned cap_f, const uint32_t* rec_count, float inv_xy, float inv_z, int id_bits,
+             const uint32_t* order)  // order: the frame of every workgroup (k_frame_order), or null
 {
   __shared__ __attribute__((aligned(16))) unsigned s_mem[kRankLds];
   __shared__ unsigned s_w[kRankBlock / kWave + 1];
   unsigned* bitmap = s_mem;             // kBmWords
   unsigned* prefix = s_mem + kBmWords;  // kPfxWords
   unsigned* counters = s_mem;           // kCntCap (after the ranks have been written)
-  const int f = blockIdx.x;
+  const int f = order ? (int)order[blockIdx.x] : (int)blockIdx.x;
   const unsigned tid = threadIdx.x;
   const unsigned rec_base = DENSE ? (unsigned)f * cap_f : grp_off[(size_t)f * cpf];
   const unsigned n_rec = DENSE ? min(rec_count[(size_t)f * kCountStride], cap_f) : grp_off[(size_t)(f + 1) * cpf] - rec_base;
@@ -286,11 +287,11 @@ k_frame_vox_scan(FrameInfo* fi, int n_frames, const uint32_t* vox_cnt, uint32_t*
 // (columns + 1) fits kCntCap counters.  grid = n_frames, block = kRankBlock.
 __global__ void __launch_bounds__(kRankBlock)
 k_column_index(const float4* vox, const FrameInfo* fi, int n_frames, float inv_xy, unsigned n_vox_total,
-               unsigned total_cols, uint32_t* col_first, uint32_t* idx_tmp, float4* spt)
+               unsigned total_cols, uint32_t* col_first, uint32_t* idx_tmp, float4* spt, const uint32_t* order)
 {
   extern __shared__ unsigned s_cnt[];  // the batch's largest table (Globals::max_cols entries, at most kCntCap): two workgroups per CU when it is small
   __shared__ unsigned s_w[kRankBlock / kWave + 1];
-  const FrameInfo& F = fi[blockIdx.x];
+  const FrameInfo& F = fi[order ? order[blockIdx.x] : blockIdx.x];
   const unsigned tid = threadIdx.x;
   const int dx = F.div_b[0], dy = F.div_b[1];
   const unsigned T = (unsigned)(dx * dy) + 1u;  // (the last entry closes the frame's part of the table)
