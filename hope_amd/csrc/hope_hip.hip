@@ -1116,11 +1116,11 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
     gate_fused = c->own_lo == 0u && c->own_hi == 0xffffffffu && c->ablate == 0;
     uint32_t* ff = gate_fused ? flags : nullptr;
     if (c->normals_cap_small)
-      hipLaunchKernelGGL((k_normals_direct<2>), dim3(nblk(n_vox)), dim3(kBlock), 0, s, spt, col_first, c->d_fi, c->inv_xy,
+      hipLaunchKernelGGL((k_normals_direct<2>), dim3((nblk(n_vox) + 7u) / 8u * 8u), dim3(kBlock), 0, s, spt, col_first, c->d_fi, c->inv_xy,
                          c->inv_z, c->radius, c->r2, c->ring, c->own_lo, c->own_hi, (unsigned)n_vox, vf, d_normals,
                          c->ablate % 10, c->th_norm, ff, sflags);
     else
-      hipLaunchKernelGGL((k_normals_direct<kNbCap>), dim3(nblk(n_vox)), dim3(kBlock), 0, s, spt, col_first, c->d_fi,
+      hipLaunchKernelGGL((k_normals_direct<kNbCap>), dim3((nblk(n_vox) + 7u) / 8u * 8u), dim3(kBlock), 0, s, spt, col_first, c->d_fi,
                          c->inv_xy, c->inv_z, c->radius, c->r2, c->ring, c->own_lo, c->own_hi, (unsigned)n_vox, vf,
                          d_normals, c->ablate % 10, c->th_norm, ff, sflags);
   } else {
@@ -1237,11 +1237,11 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   } else if (c->knn_direct) {
     const int* ff = F == 1 ? nullptr : fit_frame;
     if (K <= 8)
-      hipLaunchKernelGGL((k_knn_direct<8>), dim3(nblk(n_fit)), dim3(kBlock), 0, s, spt_fit, col_first_fit, c->d_fi, ff,
+      hipLaunchKernelGGL((k_knn_direct<8>), dim3((nblk(n_fit) + 7u) / 8u * 8u), dim3(kBlock), 0, s, spt_fit, col_first_fit, c->d_fi, ff,
                          c->inv_xy, c->inv_z, c->cfg.th_xy, K, fit_idx, c->own_lo, c->own_hi, n_fit, knn, todo,
                          &c->d_glob->n_todo);
     else
-      hipLaunchKernelGGL((k_knn_direct<kMaxKnn>), dim3(nblk(n_fit)), dim3(kBlock), 0, s, spt_fit, col_first_fit, c->d_fi,
+      hipLaunchKernelGGL((k_knn_direct<kMaxKnn>), dim3((nblk(n_fit) + 7u) / 8u * 8u), dim3(kBlock), 0, s, spt_fit, col_first_fit, c->d_fi,
                          ff, c->inv_xy, c->inv_z, c->cfg.th_xy, K, fit_idx, c->own_lo, c->own_hi, n_fit, knn, todo,
                          &c->d_glob->n_todo);
   } else {

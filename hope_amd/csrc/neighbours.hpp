@@ -915,6 +915,14 @@ k_normals_tile(const float4* spt, const uint32_t* col_first, const FrameInfo* fi
 // clutter) do not fit: straight from HBM then, block by block.
 constexpr int kWinCap = 1024;  // 16 KiB of points + 16 KiB of 16-bit notes = the 32 KiB of 32-bit notes of the other path
 
+// Workgroups are dealt to the eight XCDs in turn, each with its own L2: a workgroup's window of the sorted array
+// overlaps its neighbours', so XCD x takes the x-th eighth of the blocks, in order (block of this workgroup).
+__device__ __forceinline__ unsigned xcd_block()
+{
+  const unsigned per = (gridDim.x + 7u) / 8u;
+  return (blockIdx.x % 8u) * per + blockIdx.x / 8u;  // (may be >= gridDim.x: its queries are then out of range)
+}
+
 template <int CAPL>
 __global__ void __launch_bounds__(kBlock, 4)
 k_normals_direct(const float4* spt, const uint32_t* col_first, const FrameInfo* fi, float inv_xy, float inv_z,
@@ -932,7 +940,7 @@ k_normals_direct(const float4* spt, const uint32_t* col_first, const FrameInfo* 
   constexpr int kWinBytes = kWinCap * 16 + CAPL * kBlock * 2;
   __shared__ __attribute__((aligned(16))) unsigned char s_raw[kNoteBytes > kWinBytes ? kNoteBytes : kWinBytes];
   __shared__ unsigned s_w[2];
-  const unsigned e = blockIdx.x * kBlock + threadIdx.x;
+  const unsigned e = xcd_block() * kBlock + threadIdx.x;
   float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
   unsigned idx = 0u;
   bool valid = e < n;
@@ -1234,7 +1242,7 @@ k_knn_direct(const float4* spt_fit, const uint32_t* col_first_fit, const FrameIn
   constexpr int kWinCap = 1536;  // (k-NN: no notes, so LDS has room for more than the normals kernel's 1024)
   __shared__ float4 s_pt[kWinCap];
   __shared__ unsigned s_w[2];
-  const unsigned e0 = blockIdx.x * kBlock + threadIdx.x;
+  const unsigned e0 = xcd_block() * kBlock + threadIdx.x;
   bool valid = e0 < n_fit;
   float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
   int me = 0;
