@@ -1301,7 +1301,7 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
                          total_ccols, zbits, ccol_first);
       hipLaunchKernelGGL(k_gather_coarse, dim3(nblk(n_fit)), dim3(kBlock), 0, s, fit_pt, qv_out, n_fit, cspt);
       if (K <= 8 && c->todo_threads)  // many queries: a thread each
-        hipLaunchKernelGGL((k_knn_todo_threads<8>), dim3(nblk(n_todo)), dim3(kBlock), 0, s, todo, &c->d_glob->n_todo,
+        hipLaunchKernelGGL((k_knn_todo_threads<8>), dim3((nblk(n_todo) + 7u) / 8u * 8u), dim3(kBlock), 0, s, todo, &c->d_glob->n_todo,
                            fit_pt, fit_frame, cspt, ccol_first, c->d_fi, c->inv_xy, c->inv_z, c->cfg.th_xy, kCoarse, K,
                            knn);
       else if (K <= 8)

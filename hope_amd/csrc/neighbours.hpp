@@ -1461,7 +1461,7 @@ k_knn_todo_threads(const uint32_t* todo, const unsigned* n_todo, const float4* f
                    const float4* idx_pt, const uint32_t* idx_first, const FrameInfo* fi, float inv_xy, float inv_z,
                    float cell_xy, int coarse, int K, int* knn_out)
 {
-  const unsigned t = blockIdx.x * kBlock + threadIdx.x;
+  const unsigned t = xcd_block() * kBlock + threadIdx.x;  // (neighbours in the list are neighbours in space)
   if (t >= *n_todo) return;
   const uint32_t entry = todo[t];
   const int me = (int)(entry & ~kTodoFromRing0);
