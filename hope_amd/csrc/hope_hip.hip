@@ -1325,6 +1325,7 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   ALLOC(root, int, n_fit);
   ALLOC(label, int, n_fit);
   const unsigned gb = nblk(n_fit);
+  const unsigned gb8 = (gb + 7u) / 8u * 8u;  // (kernels that map their blocks with xcd_block())
   pm = prof_mark(c);
   hipLaunchKernelGGL(k_seed_ranks, dim3(gb), dim3(kBlock), 0, s, c->d_fi, fit_frame, n_fit, rank, seed_node, parent,
                      L);
@@ -1346,13 +1347,13 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   else
     hipLaunchKernelGGL(k_union_local<false>, uf_grid, dim3(kUfBlock), uf_lds, s, knn, fit_pt, c->d_fi, K, c->cfg.th_z,
                        parent, cross, edges, d_n_edges, (const uint32_t*)nullptr);  // (frame order: 0.76 -> 0.83 ms here)
-  hipLaunchKernelGGL(k_union_cross, dim3(gb), dim3(kBlock), 0, s, knn, cross, n_fit, K, parent, (c->ablate / 100) % 10);
-  hipLaunchKernelGGL(k_flatten_roots, dim3(gb), dim3(kBlock), 0, s, parent, rank, n_fit, root, L);
+  hipLaunchKernelGGL(k_union_cross, dim3(gb8), dim3(kBlock), 0, s, knn, cross, n_fit, K, parent, (c->ablate / 100) % 10);
+  hipLaunchKernelGGL(k_flatten_roots, dim3(gb8), dim3(kBlock), 0, s, parent, rank, n_fit, root, L);
   if (K == 8)
-    hipLaunchKernelGGL(k_cross_edges<true>, dim3(gb), dim3(kBlock), 0, s, knn, fit_pt, root, fit_frame, c->d_fi, n_fit, K,
+    hipLaunchKernelGGL(k_cross_edges<true>, dim3(gb8), dim3(kBlock), 0, s, knn, fit_pt, root, fit_frame, c->d_fi, n_fit, K,
                        c->cfg.th_z, edges, d_n_edges);
   else
-    hipLaunchKernelGGL(k_cross_edges<false>, dim3(gb), dim3(kBlock), 0, s, knn, fit_pt, root, fit_frame, c->d_fi, n_fit,
+    hipLaunchKernelGGL(k_cross_edges<false>, dim3(gb8), dim3(kBlock), 0, s, knn, fit_pt, root, fit_frame, c->d_fi, n_fit,
                        K, c->cfg.th_z, edges, d_n_edges);
   prof_close(c, ST_LABELS, pm, (2.0 * 4.0 * K + 2.0 * 16.0 + 6 * 4.0) * n_fit);
   const unsigned ge = std::min(gb, 2048u);
@@ -1390,7 +1391,7 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   ALLOC(seg_scan, U3, (size_t)n_fit + 1);
   pm = prof_mark(c);
   HIPCHK(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * ((size_t)n_fit + 1), s));
-  hipLaunchKernelGGL(k_segment_sizes, dim3(gb), dim3(kBlock), 0, s, root, L, n_fit, label, cnt);
+  hipLaunchKernelGGL(k_segment_sizes, dim3(gb8), dim3(kBlock), 0, s, root, L, n_fit, label, cnt);
   hipLaunchKernelGGL(k_segment_flags, dim3(nblk((size_t)n_fit + 1)), dim3(kBlock), 0, s, cnt, n_fit,
                      c->cfg.min_cluster, seg_flags);
   HIPCHK(exclusive_scan_u32x3(pa, seg_flags, seg_scan, (size_t)n_fit + 1, s));

@@ -156,6 +156,15 @@ __device__ __forceinline__ unsigned long long match_lanes(unsigned d, int bits, 
   return same;
 }
 
+// Workgroups are dealt to the eight XCDs in turn, each with its own L2: kernels whose neighbouring
+// blocks read the same lines (windows of the sorted array, the rows and roots of neighbours in index) let XCD x take
+// the x-th eighth of the blocks, in order.  The grid must be a multiple of 8 blocks (grid8).
+__device__ __forceinline__ unsigned xcd_block()
+{
+  const unsigned per = (gridDim.x + 7u) / 8u;
+  return (blockIdx.x % 8u) * per + blockIdx.x / 8u;  // (may be >= gridDim.x: its queries are then out of range)
+}
+
 // ---- K1: bbox + count per frame ------------------------------------------------------
 // pcl::getMinMax3D inside VoxelGrid::applyFilter.  grid = (blocks, n_frames).
 template <class Src>
@@ -1076,7 +1085,7 @@ k_union_local(const int* knn, const float4* fit_pt, const FrameInfo* fi, int K, 
 static __global__ void __launch_bounds__(kBlock)
 k_union_cross(const int* knn, const uint32_t* cross, unsigned n_fit, int K, int* parent, int ablate)
 {
-  const unsigned g = blockIdx.x * kBlock + threadIdx.x;
+  const unsigned g = xcd_block() * kBlock + threadIdx.x;
   const uint32_t m = g < n_fit ? cross[g] : 0u;
   if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull || ablate == 2) return;
   const int lane = threadIdx.x & (kWave - 1);
@@ -1141,7 +1150,7 @@ __device__ __forceinline__ void wave_atomic_count_by_key(uint32_t* table, int ke
 static __global__ void __launch_bounds__(kBlock)
 k_flatten_roots(int* parent, const int* rank, unsigned n_fit, int* root, int* L)
 {
-  const unsigned g = blockIdx.x * kBlock + threadIdx.x;
+  const unsigned g = xcd_block() * kBlock + threadIdx.x;
   const bool active = g < n_fit;
   int r = 0, rk = 0x7fffffff;
   if (active) {
@@ -1161,7 +1170,7 @@ __global__ void __launch_bounds__(kBlock)
 k_cross_edges(const int* knn, const float4* fit_pt, const int* root, const int* fit_frame, const FrameInfo* fi,
               unsigned n_fit, int K, float th_z, uint2* edges, unsigned* n_edges)
 {
-  const unsigned g = blockIdx.x * kBlock + threadIdx.x;
+  const unsigned g = xcd_block() * kBlock + threadIdx.x;
   // (K8: the edges of a frame that fits one union tile were found by k_union_local)
   const bool live = g < n_fit && !(K8 && (unsigned)fi[fit_frame[g]].n_fit <= (unsigned)kUfTile);
   if (__builtin_amdgcn_ballot_w64(live) == 0ull) return;
@@ -1251,7 +1260,7 @@ k_label_shortcut(const int* root, const int* seed_node, unsigned n_fit, int* L, 
 static __global__ void __launch_bounds__(kBlock)
 k_segment_sizes(const int* root, const int* L, unsigned n_fit, int* label, uint32_t* cnt)
 {
-  const unsigned g = blockIdx.x * kBlock + threadIdx.x;
+  const unsigned g = xcd_block() * kBlock + threadIdx.x;
   const bool active = g < n_fit;
   int a = 0;
   if (active) {

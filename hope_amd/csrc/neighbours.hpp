@@ -915,14 +915,6 @@ k_normals_tile(const float4* spt, const uint32_t* col_first, const FrameInfo* fi
 // clutter) do not fit: straight from HBM then, block by block.
 constexpr int kWinCap = 1024;  // 16 KiB of points + 16 KiB of 16-bit notes = the 32 KiB of 32-bit notes of the other path
 
-// Workgroups are dealt to the eight XCDs in turn, each with its own L2: a workgroup's window of the sorted array
-// overlaps its neighbours', so XCD x takes the x-th eighth of the blocks, in order (block of this workgroup).
-__device__ __forceinline__ unsigned xcd_block()
-{
-  const unsigned per = (gridDim.x + 7u) / 8u;
-  return (blockIdx.x % 8u) * per + blockIdx.x / 8u;  // (may be >= gridDim.x: its queries are then out of range)
-}
-
 template <int CAPL>
 __global__ void __launch_bounds__(kBlock, 4)
 k_normals_direct(const float4* spt, const uint32_t* col_first, const FrameInfo* fi, float inv_xy, float inv_z,
