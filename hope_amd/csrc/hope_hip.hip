@@ -261,6 +261,7 @@ struct hope_ctx {
   bool one_pass = false;          // this call's records are in d_slots
   bool dense = false;             // ... densely per frame (k_bbox_records<.., DENSE>), cap_f records at most; else kChunk slots per chunk
   int members_by_frame = 1;       // HOPE_DEBUG_MEMBERS_SORT=1: the member lists by radix sort always; 0: by frame always
+  int union_small_tiles = 1;      // HOPE_DEBUG_UNION_TILES=0: a single cloud is united in tiles of 24 576 points too
   int frame_order = 1;            // HOPE_DEBUG_FRAME_ORDER=0: the per-frame kernels take the frames in frame order
   int dense_records = 1;          // HOPE_DEBUG_DENSE_RECORDS=0: the sparse slots + k_group_keys
   int cap_mul = 16;               // HOPE_DEBUG_CAP_MUL: records per chunk that a frame's dense range has room for
@@ -1334,8 +1335,15 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   ALLOC(cross, uint32_t, n_fit);
   ALLOC(edges, uint2, (size_t)n_fit * K);
   unsigned* d_n_edges = &c->d_glob->n_runs;  // free again after the voxel stage
-  const dim3 uf_grid(std::max(1u, nblk(max_fit, kUfTile)), F);
-  const size_t uf_lds = sizeof(int) * std::min<size_t>(kUfTile, std::max<size_t>(max_fit, 1));  // the largest tile
+  // tiles of a frame: as large as LDS allows, except that a single cloud (38 tiles of 24 576 points for the 10^8-point
+  // scene: 38 of 256 CUs at work) is cut so that there are two tiles per CU
+  unsigned uf_tile = (unsigned)kUfTile;
+  if (F == 1 && c->union_small_tiles && max_fit > 4u * (unsigned)kUfTile)
+    uf_tile = c->union_small_tiles >= kUfBlock
+                  ? std::min<unsigned>(kUfTile, (unsigned)c->union_small_tiles / kUfBlock * kUfBlock)
+                  : std::min<unsigned>(kUfTile, std::max<unsigned>(4096u, (max_fit / 512u + kUfBlock - 1u) / kUfBlock * kUfBlock));
+  const dim3 uf_grid(std::max(1u, nblk(max_fit, (int)uf_tile)), F);
+  const size_t uf_lds = sizeof(int) * std::min<size_t>(uf_tile, std::max<size_t>(max_fit, 1));  // the largest tile
   HIPCHK(hipMemsetAsync(d_n_edges, 0, sizeof(unsigned), s));
   if (uf_lds > ((size_t)48 << 10))
     HIPCHK(hipFuncSetAttribute(K == 8 ? reinterpret_cast<const void*>(&k_union_local<true>)
@@ -1343,18 +1351,19 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)uf_lds));
   if (K == 8)
     hipLaunchKernelGGL(k_union_local<true>, uf_grid, dim3(kUfBlock), uf_lds, s, knn, fit_pt, c->d_fi, K, c->cfg.th_z,
-                       parent, cross, edges, d_n_edges, (const uint32_t*)nullptr);  // (frame order: 0.76 -> 0.83 ms here)
+                       parent, cross, edges, d_n_edges, (const uint32_t*)nullptr, uf_tile);  // (frame order: 0.76 -> 0.83 ms here)
   else
     hipLaunchKernelGGL(k_union_local<false>, uf_grid, dim3(kUfBlock), uf_lds, s, knn, fit_pt, c->d_fi, K, c->cfg.th_z,
-                       parent, cross, edges, d_n_edges, (const uint32_t*)nullptr);  // (frame order: 0.76 -> 0.83 ms here)
+                       parent, cross, edges, d_n_edges, (const uint32_t*)nullptr, uf_tile);  // (frame order: 0.76 -> 0.83 ms here)
   hipLaunchKernelGGL(k_union_cross, dim3(gb8), dim3(kBlock), 0, s, knn, cross, n_fit, K, parent, (c->ablate / 100) % 10);
-  hipLaunchKernelGGL(k_flatten_roots, dim3(gb8), dim3(kBlock), 0, s, parent, rank, n_fit, root, L);
+  hipLaunchKernelGGL(k_flatten_roots, dim3((nblk(n_fit, kBlock * kSizeRun) + 7u) / 8u * 8u), dim3(kBlock), 0, s, parent, rank,
+                     n_fit, root, L);
   if (K == 8)
     hipLaunchKernelGGL(k_cross_edges<true>, dim3(gb8), dim3(kBlock), 0, s, knn, fit_pt, root, fit_frame, c->d_fi, n_fit, K,
-                       c->cfg.th_z, edges, d_n_edges);
+                       c->cfg.th_z, edges, d_n_edges, uf_tile);
   else
     hipLaunchKernelGGL(k_cross_edges<false>, dim3(gb8), dim3(kBlock), 0, s, knn, fit_pt, root, fit_frame, c->d_fi, n_fit,
-                       K, c->cfg.th_z, edges, d_n_edges);
+                       K, c->cfg.th_z, edges, d_n_edges, uf_tile);
   prof_close(c, ST_LABELS, pm, (2.0 * 4.0 * K + 2.0 * 16.0 + 6 * 4.0) * n_fit);
   const unsigned ge = std::min(gb, 2048u);
   // Sweeps until a whole (shortcut, sweep) pair changes nothing.  Only the last pair of a batch is
@@ -1391,7 +1400,8 @@ int stage_rest(hope_ctx* c, float4* d_vox, int* d_vox_frame, int zbits, int key2
   ALLOC(seg_scan, U3, (size_t)n_fit + 1);
   pm = prof_mark(c);
   HIPCHK(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * ((size_t)n_fit + 1), s));
-  hipLaunchKernelGGL(k_segment_sizes, dim3(gb8), dim3(kBlock), 0, s, root, L, n_fit, label, cnt);
+  hipLaunchKernelGGL(k_segment_sizes, dim3((nblk(n_fit, kBlock * kSizeRun) + 7u) / 8u * 8u), dim3(kBlock), 0, s, root, L,
+                     n_fit, label, cnt);
   hipLaunchKernelGGL(k_segment_flags, dim3(nblk((size_t)n_fit + 1)), dim3(kBlock), 0, s, cnt, n_fit,
                      c->cfg.min_cluster, seg_flags);
   HIPCHK(exclusive_scan_u32x3(pa, seg_flags, seg_scan, (size_t)n_fit + 1, s));
@@ -1775,6 +1785,8 @@ HOPE_API int hope_create(const hope_config* cfg, hope_ctx** out)
   c->members_by_frame = knob ? (knob[0] == '1' ? 0 : 2) : 1;
   knob = debug_env("HOPE_DEBUG_FRAME_ORDER");
   c->frame_order = (knob && knob[0] == '0') ? 0 : 1;
+  knob = debug_env("HOPE_DEBUG_UNION_TILES");
+  c->union_small_tiles = knob ? atoi(knob) : 1;  // (a number of points from kUfBlock up: that tile)
   knob = debug_env("HOPE_DEBUG_TIMELINE");
   c->timeline = (knob && knob[0] == '1') ? 1 : 0;
   knob = debug_env("HOPE_DEBUG_SEGSORT");

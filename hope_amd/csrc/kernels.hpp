@@ -915,7 +915,8 @@ __device__ __forceinline__ bool z_edge(const float4* fit_pt, int a, int b, float
 // is noted as a bit mask per point and united in global memory by k_union_cross.
 constexpr int kUfBlock = 1024;
 constexpr int kUfPer = 24;
-constexpr int kUfTile = kUfBlock * kUfPer;  // 24576 points, 96 KiB of LDS: one workgroup per CU
+constexpr int kUfTile = kUfBlock * kUfPer;  // 24576 points, 96 KiB of LDS: one workgroup per CU (the largest tile; the
+                                            // launch chooses: a single cloud takes smaller tiles, one per CU and more)
 
 __device__ __forceinline__ int uf_find_lds(int* parent, int x)
 {
@@ -980,15 +981,15 @@ __device__ __forceinline__ uint32_t mutual_edges_up(const int* knn, const float4
 template <bool K8>
 __global__ void __launch_bounds__(kUfBlock)
 k_union_local(const int* knn, const float4* fit_pt, const FrameInfo* fi, int K, float th_z, int* parent, uint32_t* cross,
-              uint2* edges, unsigned* n_edges, const uint32_t* order)
+              uint2* edges, unsigned* n_edges, const uint32_t* order, unsigned tile)
 {
   // (dynamic: as many entries as the batch's largest tile has points, so that frames of a few thousand fit points
   // leave room for two workgroups per CU -- the kernel waits on gathers and LDS chases, not on issue)
   extern __shared__ int s_par[];
   const FrameInfo& F = fi[order ? order[blockIdx.y] : blockIdx.y];
-  if (blockIdx.x * (unsigned)kUfTile >= (unsigned)F.n_fit) return;
-  const unsigned base = (unsigned)F.fit_start + blockIdx.x * (unsigned)kUfTile;
-  const unsigned end = min(base + (unsigned)kUfTile, (unsigned)(F.fit_start + F.n_fit));
+  if (blockIdx.x * tile >= (unsigned)F.n_fit) return;
+  const unsigned base = (unsigned)F.fit_start + blockIdx.x * tile;
+  const unsigned end = min(base + tile, (unsigned)(F.fit_start + F.n_fit));
   for (unsigned i = threadIdx.x; i < end - base; i += kUfBlock) s_par[i] = (int)i;
   __syncthreads();
   for (int i = 0; i < kUfPer; ++i) {
@@ -1041,7 +1042,7 @@ k_union_local(const int* knn, const float4* fit_pt, const FrameInfo* fi, int K, 
   // A frame that fits one tile has its final components here, in LDS: the valid one-way edges
   // between two different components (all the label sweeps need) are found with LDS look-ups of the
   // roots instead of k_cross_edges' gathers.
-  if (!K8 || (unsigned)F.n_fit > (unsigned)kUfTile) return;
+  if (!K8 || (unsigned)F.n_fit > tile) return;
   __syncthreads();
   const int lane = threadIdx.x & (kWave - 1);
   for (int i = 0; i < kUfPer; ++i) {  // (uniform trip count: the loop holds wave-wide votes)
@@ -1063,18 +1064,25 @@ k_union_local(const int* knn, const float4* fit_pt, const FrameInfo* fi, int K, 
       rv[j] = use ? s_par[nb[j] - (int)base] : r;
       zv[j] = (use && rv[j] != r) ? fit_pt[nb[j]].z : NAN;
     }
+    bool emit[8];
+    unsigned long long ems[8];
+    unsigned total = 0u;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const bool emit = rv[j] != r && fabsf(zg - zv[j]) < th_z;
-      const unsigned long long em = __builtin_amdgcn_ballot_w64(emit);
-      if (em) {
-        unsigned o = 0;
-        if (lane == __ffsll((long long)em) - 1) o = atomicAdd(n_edges, (unsigned)__popcll(em));
-        o = (unsigned)__shfl((int)o, __ffsll((long long)em) - 1);
-        if (emit)
-          edges[o + (unsigned)__popcll(em & ((1ull << lane) - 1ull))] =
-              make_uint2(base + (unsigned)r, base + (unsigned)rv[j]);
-      }
+      emit[j] = rv[j] != r && fabsf(zg - zv[j]) < th_z;
+      ems[j] = __builtin_amdgcn_ballot_w64(emit[j]);
+      total += (unsigned)__popcll(ems[j]);
+    }
+    if (total == 0u) continue;
+    unsigned o = 0u;  // (one place in the list for the edges of all eight columns)
+    if (lane == 0) o = atomicAdd(n_edges, total);
+    o = (unsigned)__builtin_amdgcn_readfirstlane((int)o);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (emit[j])
+        edges[o + (unsigned)__popcll(ems[j] & ((1ull << lane) - 1ull))] =
+            make_uint2(base + (unsigned)r, base + (unsigned)rv[j]);
+      o += (unsigned)__popcll(ems[j]);
     }
   }
 }
@@ -1095,23 +1103,25 @@ k_union_cross(const int* knn, const uint32_t* cross, unsigned n_fit, int K, int*
     unsigned long long todo = __builtin_amdgcn_ballot_w64(on);
     if (!todo) continue;
     const int rb = on ? parent[knn[(size_t)g * K + j]] : 0;
+    bool first = false;  // the first lane of each distinct pair: those unite, all at once (the finds are chains of loads)
     while (todo) {
       const int leader = __ffsll((long long)todo) - 1;
-      const int la = __shfl(ra, leader), lb = __shfl(rb, leader);
+      const int la = __builtin_amdgcn_readlane(ra, leader), lb = __builtin_amdgcn_readlane(rb, leader);
       todo &= ~__builtin_amdgcn_ballot_w64(on && ra == la && rb == lb);
-      if (lane == leader && ablate != 1) {
-        int a = la, b = lb;
-        while (true) {
-          a = uf_find(parent, a);
-          b = uf_find(parent, b);
-          if (a == b) break;
-          if (a > b) {
-            const int t = a;
-            a = b;
-            b = t;
-          }
-          if (atomicCAS(&parent[b], b, a) == b) break;
+      first |= lane == leader;
+    }
+    if (first && ra != rb && ablate != 1) {
+      int a = ra, b = rb;
+      while (true) {
+        a = uf_find(parent, a);
+        b = uf_find(parent, b);
+        if (a == b) break;
+        if (a > b) {
+          const int t = a;
+          a = b;
+          b = t;
         }
+        if (atomicCAS(&parent[b], b, a) == b) break;
       }
     }
   }
@@ -1147,19 +1157,58 @@ __device__ __forceinline__ void wave_atomic_count_by_key(uint32_t* table, int ke
   }
 }
 
+// A wave takes kSizeRun consecutive chunks of 64 points: the chains of the run are chased together, and a minimum goes
+// to L[] when the root changes, not per chunk -- neighbouring points share their component, and the components of a
+// single cloud are few and large (one address for the atomics of every wave of the floor).
+constexpr int kSizeRun = 8;
 static __global__ void __launch_bounds__(kBlock)
 k_flatten_roots(int* parent, const int* rank, unsigned n_fit, int* root, int* L)
 {
-  const unsigned g = xcd_block() * kBlock + threadIdx.x;
-  const bool active = g < n_fit;
-  int r = 0, rk = 0x7fffffff;
-  if (active) {
-    r = (int)g;
-    while (parent[r] != r) r = parent[r];
-    root[g] = r;
-    rk = rank[g];
+  const int lane = threadIdx.x & (kWave - 1);
+  const unsigned wave = xcd_block() * (kBlock / kWave) + threadIdx.x / kWave;
+  if (wave * (unsigned)(kWave * kSizeRun) >= n_fit) return;
+  const unsigned g0 = wave * (unsigned)(kWave * kSizeRun) + (unsigned)lane;
+  int r[kSizeRun], rk[kSizeRun];
+#pragma unroll
+  for (int i = 0; i < kSizeRun; ++i) {
+    const unsigned g = g0 + i * kWave;
+    r[i] = g < n_fit ? parent[g] : -1;
+    rk[i] = g < n_fit ? rank[g] : 0x7fffffff;
   }
-  wave_atomic_min_by_key(L, r, rk, active);
+  bool more = true;
+  while (more) {
+    more = false;
+    int p[kSizeRun];
+#pragma unroll
+    for (int i = 0; i < kSizeRun; ++i) p[i] = r[i] >= 0 ? parent[r[i]] : -1;
+#pragma unroll
+    for (int i = 0; i < kSizeRun; ++i) {
+      more |= p[i] != r[i];
+      r[i] = p[i];
+    }
+  }
+  int run_key = -1, run_min = 0x7fffffff;
+#pragma unroll
+  for (int i = 0; i < kSizeRun; ++i) {
+    const bool active = r[i] >= 0;
+    if (active) root[g0 + i * kWave] = r[i];
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(active);
+    while (todo) {
+      const int k = __builtin_amdgcn_readlane(r[i], __ffsll((long long)todo) - 1);
+      const bool mine = active && r[i] == k;
+      int m = mine ? rk[i] : 0x7fffffff;
+#pragma unroll
+      for (int off = kWave / 2; off > 0; off >>= 1) m = min(m, __shfl_xor(m, off));
+      if (k != run_key) {
+        if (run_key >= 0 && lane == 0) atomicMin(&L[run_key], run_min);
+        run_key = k;
+        run_min = 0x7fffffff;
+      }
+      run_min = min(run_min, m);
+      todo &= ~__builtin_amdgcn_ballot_w64(mine);
+    }
+  }
+  if (run_key >= 0 && lane == 0) atomicMin(&L[run_key], run_min);
 }
 
 // The valid directed edges that join two DIFFERENT mutual components are the only ones the label
@@ -1168,11 +1217,11 @@ k_flatten_roots(int* parent, const int* rank, unsigned n_fit, int* root, int* L)
 template <bool K8>
 __global__ void __launch_bounds__(kBlock)
 k_cross_edges(const int* knn, const float4* fit_pt, const int* root, const int* fit_frame, const FrameInfo* fi,
-              unsigned n_fit, int K, float th_z, uint2* edges, unsigned* n_edges)
+              unsigned n_fit, int K, float th_z, uint2* edges, unsigned* n_edges, unsigned tile)
 {
   const unsigned g = xcd_block() * kBlock + threadIdx.x;
   // (K8: the edges of a frame that fits one union tile were found by k_union_local)
-  const bool live = g < n_fit && !(K8 && (unsigned)fi[fit_frame[g]].n_fit <= (unsigned)kUfTile);
+  const bool live = g < n_fit && !(K8 && (unsigned)fi[fit_frame[g]].n_fit <= tile);
   if (__builtin_amdgcn_ballot_w64(live) == 0ull) return;
   const int r = live ? root[g] : 0;
   const float zg = live ? fit_pt[g].z : 0.f;
@@ -1207,8 +1256,22 @@ k_cross_edges(const int* knn, const float4* fit_pt, const int* root, const int* 
       any |= em[j];
     }
     if (__builtin_amdgcn_ballot_w64(any) == 0ull) return;
+    // one place in the list for the wave's edges of all eight columns (the counter is one address for every wave)
+    unsigned long long ems[8];
+    unsigned total = 0u;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) emit_edge(em[j], rv[j]);
+    for (int j = 0; j < 8; ++j) {
+      ems[j] = __builtin_amdgcn_ballot_w64(em[j]);
+      total += (unsigned)__popcll(ems[j]);
+    }
+    unsigned o = 0u;
+    if (lane == 0) o = atomicAdd(n_edges, total);
+    o = (unsigned)__builtin_amdgcn_readfirstlane((int)o);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (em[j]) edges[o + (unsigned)__popcll(ems[j] & ((1ull << lane) - 1ull))] = make_uint2((unsigned)r, (unsigned)rv[j]);
+      o += (unsigned)__popcll(ems[j]);
+    }
   } else {
     for (int j = 0; j < K; ++j) {
       bool emit = false;
@@ -1256,18 +1319,41 @@ k_label_shortcut(const int* root, const int* seed_node, unsigned n_fit, int* L, 
   }
 }
 
-// per rank value: number of points whose segment was seeded at that rank
+// per rank value: number of points whose segment was seeded at that rank.  A wave takes kSizeRun consecutive chunks of
+// 64 points and adds a count when the label changes, not per chunk: neighbouring points share their segment, and the
+// segments of a single cloud are few and large (one address for the adds of every wave of the floor).
 static __global__ void __launch_bounds__(kBlock)
 k_segment_sizes(const int* root, const int* L, unsigned n_fit, int* label, uint32_t* cnt)
 {
-  const unsigned g = xcd_block() * kBlock + threadIdx.x;
-  const bool active = g < n_fit;
-  int a = 0;
-  if (active) {
-    a = L[root[g]];
-    label[g] = a;
+  const int lane = threadIdx.x & (kWave - 1);
+  const unsigned wave = xcd_block() * (kBlock / kWave) + threadIdx.x / kWave;
+  const unsigned g0 = wave * (unsigned)(kWave * kSizeRun) + (unsigned)lane;
+  if (wave * (unsigned)(kWave * kSizeRun) >= n_fit) return;
+  int a[kSizeRun];
+#pragma unroll
+  for (int i = 0; i < kSizeRun; ++i) a[i] = g0 + i * kWave < n_fit ? root[g0 + i * kWave] : -1;
+#pragma unroll
+  for (int i = 0; i < kSizeRun; ++i) a[i] = a[i] >= 0 ? L[a[i]] : -1;
+  int run_key = -1;
+  uint32_t run_cnt = 0u;
+#pragma unroll
+  for (int i = 0; i < kSizeRun; ++i) {
+    const bool active = a[i] >= 0;  // (labels are seed ranks, >= 0)
+    if (active) label[g0 + i * kWave] = a[i];
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(active);
+    while (todo) {
+      const int k = __builtin_amdgcn_readlane(a[i], __ffsll((long long)todo) - 1);
+      const unsigned long long grp = __builtin_amdgcn_ballot_w64(active && a[i] == k);
+      if (k != run_key) {
+        if (run_cnt && lane == 0) atomicAdd(&cnt[run_key], run_cnt);
+        run_key = k;
+        run_cnt = 0u;
+      }
+      run_cnt += (uint32_t)__popcll(grp);
+      todo &= ~grp;
+    }
   }
-  wave_atomic_count_by_key(cnt, a, active);
+  if (run_cnt && lane == 0) atomicAdd(&cnt[run_key], run_cnt);
 }
 
 static __global__ void __launch_bounds__(kBlock)
