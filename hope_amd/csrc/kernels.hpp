@@ -1087,6 +1087,8 @@ k_union_local(const int* knn, const float4* fit_pt, const FrameInfo* fi, int K, 
   }
 }
 
+constexpr int kKeyVotes = 3;  // keys of a chunk that are gathered by a vote each; the lanes left after these go alone
+
 // The mutual edges that leave a tile.  k_union_local has left parent[] flattened per tile, so an
 // edge (g, v) only says "unite tile component parent[g] with tile component parent[v]"; the many
 // edges along the cut of one surface all name the same pair, so each wave unites a pair once.
@@ -1193,7 +1195,7 @@ k_flatten_roots(int* parent, const int* rank, unsigned n_fit, int* root, int* L)
     const bool active = r[i] >= 0;
     if (active) root[g0 + i * kWave] = r[i];
     unsigned long long todo = __builtin_amdgcn_ballot_w64(active);
-    while (todo) {
+    for (int vote = 0; todo && vote < kKeyVotes; ++vote) {
       const int k = __builtin_amdgcn_readlane(r[i], __ffsll((long long)todo) - 1);
       const bool mine = active && r[i] == k;
       int m = mine ? rk[i] : 0x7fffffff;
@@ -1207,6 +1209,7 @@ k_flatten_roots(int* parent, const int* rank, unsigned n_fit, int* root, int* L)
       run_min = min(run_min, m);
       todo &= ~__builtin_amdgcn_ballot_w64(mine);
     }
+    if ((todo >> lane) & 1ull) atomicMin(&L[r[i]], rk[i]);  // (clutter: as many components as points, no two alike)
   }
   if (run_key >= 0 && lane == 0) atomicMin(&L[run_key], run_min);
 }
@@ -1341,7 +1344,7 @@ k_segment_sizes(const int* root, const int* L, unsigned n_fit, int* label, uint3
     const bool active = a[i] >= 0;  // (labels are seed ranks, >= 0)
     if (active) label[g0 + i * kWave] = a[i];
     unsigned long long todo = __builtin_amdgcn_ballot_w64(active);
-    while (todo) {
+    for (int vote = 0; todo && vote < kKeyVotes; ++vote) {
       const int k = __builtin_amdgcn_readlane(a[i], __ffsll((long long)todo) - 1);
       const unsigned long long grp = __builtin_amdgcn_ballot_w64(active && a[i] == k);
       if (k != run_key) {
@@ -1352,6 +1355,7 @@ k_segment_sizes(const int* root, const int* L, unsigned n_fit, int* label, uint3
       run_cnt += (uint32_t)__popcll(grp);
       todo &= ~grp;
     }
+    if ((todo >> lane) & 1ull) atomicAdd(&cnt[a[i]], 1u);
   }
   if (run_cnt && lane == 0) atomicAdd(&cnt[run_key], run_cnt);
 }
