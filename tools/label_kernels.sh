@@ -7,7 +7,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for w in frames cloud; do
   rm -rf $O/prof_lk_$w
-  if [ $w = frames ]; then A="--steps 4 --warmup 2 --no-cpu-baseline --no-cloud --no-stream --no-two-ranges"; else A="--workload cloud --no-cpu-baseline"; fi
+  if [ $w = frames ]; then A="--steps 4 --warmup 2 --no-cpu-baseline --no-cloud --no-stream --no-two-ranges"; else A="--workload cloud --no-cpu-baseline"; fi; [ -n "$HIPLIB" ] && A="$A --hip-lib $R/$HIPLIB"
   timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_lk_$w -- python3 $R/bench.py $A > $O/lk_${tag}_$w.log 2>&1 || { tail -5 $O/lk_${tag}_$w.log; exit 1; }
   python3 - $O/prof_lk_$w $w <<'PY'
 import csv, glob, sys
