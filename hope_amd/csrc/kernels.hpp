@@ -903,6 +903,21 @@ __device__ __forceinline__ int uf_find(int* parent, int x)
   return x;
 }
 
+// the roots of two nodes, the two chains walked side by side: one round trip per step for both
+__device__ __forceinline__ void uf_find2(int* parent, int& a, int& b)
+{
+  int pa = parent[a], pb = parent[b];
+  while (pa != a || pb != b) {
+    const int ga = parent[pa], gb = parent[pb];  // (at a root: its own entry again)
+    if (ga != pa) parent[a] = ga;                // path halving, as in uf_find
+    if (gb != pb) parent[b] = gb;
+    a = pa;
+    pa = ga;
+    b = pb;
+    pb = gb;
+  }
+}
+
 __device__ __forceinline__ bool z_edge(const float4* fit_pt, int a, int b, float th_z)
 {
   return fabsf(fit_pt[a].z - fit_pt[b].z) < th_z;  // validatePoint, smooth mode
@@ -1016,7 +1031,7 @@ k_union_local(const int* knn, const float4* fit_pt, const FrameInfo* fi, int K, 
       }
       int a = l, b = v - (int)base;
       while (true) {
-        a = uf_find_lds(s_par, a);
+        a = uf_find_lds(s_par, a);  // (the two chains side by side, as in k_union_cross: 0.527 -> 0.547 ms)
         b = uf_find_lds(s_par, b);
         if (a == b) break;
         if (a > b) {
@@ -1115,8 +1130,7 @@ k_union_cross(const int* knn, const uint32_t* cross, unsigned n_fit, int K, int*
     if (first && ra != rb && ablate != 1) {
       int a = ra, b = rb;
       while (true) {
-        a = uf_find(parent, a);
-        b = uf_find(parent, b);
+        uf_find2(parent, a, b);
         if (a == b) break;
         if (a > b) {
           const int t = a;
